@@ -1,0 +1,301 @@
+"""Generate tests/golden/*.npz from the GENUINE reference (runs only where /root/reference exists).
+
+TEST INFRASTRUCTURE ONLY.  The reference's third-party imports that are absent from this image
+(tifffile, czifile, pytorch_msssim, skimage, timm, skopt) are replaced by empty stub modules in
+``sys.modules`` so that the reference's own torch / numpy / Pillow code runs unmodified; nothing
+from those stubs is executed for any fixture written here.  The reference is imported read-only
+(PYTHONDONTWRITEBYTECODE) and none of its source is copied: fixtures hold inputs and outputs only.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.path.insert(0, REF)
+
+    class _Absent:  # placeholder for third-party callables that no fixture executes
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            raise RuntimeError("third-party symbol absent in this image")
+
+    _stub("tifffile"), _stub("czifile")
+    _stub("pytorch_msssim", SSIM=_Absent, MS_SSIM=_Absent, ssim=_Absent())
+    _stub("skimage")
+    _stub("skimage.transform", resize=_Absent())
+    _stub("skimage.util", random_noise=_Absent())
+    _stub("skimage.filters", gaussian=_Absent())
+    _stub("skimage.metrics", peak_signal_noise_ratio=_Absent(), structural_similarity=_Absent())
+    _stub("timm"), _stub("timm.layers", LayerNorm2d=_Absent, EffectiveSEModule=_Absent, DropPath=_Absent,
+                         to_2tuple=_Absent(), trunc_normal_=_Absent())
+    _stub("timm.models", named_apply=_Absent())
+    _stub("skopt", gp_minimize=_Absent()), _stub("skopt.space", Dimension=_Absent)
+    import pssr.crappifiers, pssr.data, pssr.predict, pssr.util          # noqa: E401,F401
+    import pssr.models._blocks, pssr.models.resunet                      # noqa: E401,F401
+    return sys.modules["pssr"]
+
+
+def synth_u8(rng, c, h, w, kind="noise"):
+    if kind == "noise":
+        return rng.integers(0, 256, size=(c, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (yy * 255 // max(h - 1, 1) + xx * 3) % 256
+    img = np.stack([(base + 37 * k) % 256 for k in range(c)]).astype(np.uint8)
+    img[:, : h // 8, :] = 0
+    img[:, -h // 8:, :] = 255
+    return img
+
+
+def gen_bilinear(pssr):
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    out = {}
+    for i, (hi, lo) in enumerate([(512, 128), (256, 64), (1024, 256), (500, 125), (300, 128), (64, 16), (96, 24)]):
+        for kind in ("noise", "edges"):
+            img = synth_u8(rng, 1, hi, hi, kind)[0]
+            # exactly the call at pssr/data.py:483
+            lr = np.asarray(Image.fromarray(img).resize([lo] * 2, Image.Resampling.BILINEAR))
+            out[f"in_{i}_{kind}"] = img
+            out[f"out_{i}_{kind}"] = lr
+    np.savez_compressed(OUT / "bilinear.npz", **out)
+
+
+def gen_pairs(pssr):
+    from pssr.crappifiers import AdditiveGaussian, MultiCrappifier, Poisson
+    from pssr.data import _gen_pair
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [
+        ("ag", lambda: AdditiveGaussian(13, 0, 0), 1, 256, False),
+        ("ag_gain", lambda: AdditiveGaussian(7.5, -3, 0), 1, 256, [True, 1]),
+        ("poisson", lambda: Poisson(), 1, 256, [False, (1, 2)]),
+        ("poisson_mix", lambda: Poisson(0.5, 4, 0), 1, 256, [True, 2]),
+        ("multi", lambda: MultiCrappifier(AdditiveGaussian(13, 0, 0), Poisson()), 1, 256, [True, (1, 2)]),
+        ("pad", lambda: AdditiveGaussian(13, 0, 0), 1, 250, [False, 1]),      # 250 -> reflect-pad to 256
+        ("frames3", lambda: AdditiveGaussian(5, 0, 0), 3, 128, [True, 1]),
+        ("none", lambda: None, 1, 128, False),
+    ]
+    for name, mk, c, size, rot in cases:
+        hr_res = 256 if size > 128 else 128
+        hr = synth_u8(rng, c, size, size, "noise" if name != "pad" else "edges")
+        seed = 100 + len(out)
+        np.random.seed(seed)
+        random.seed(seed)
+        hr_t, lr_t = _gen_pair(hr, hr_res, 4, rot, mk(), None, None)
+        out[f"{name}_hr_in"] = hr
+        out[f"{name}_hr"] = hr_t.numpy()
+        out[f"{name}_lr"] = lr_t.numpy()
+        out[f"{name}_meta"] = np.array([hr_res, 4, seed, int(bool(rot)), int(rot[0]) if rot else 0,
+                                        (3 if rot[1] == (1, 2) else rot[1]) if rot else 0])
+        # re-draw the raw noise with the same seed, in the order the crappifier draws it, so that
+        # the build can check clip(round(lr+noise)) exactly without reproducing MT19937
+        lr_shape = (c, hr_res // 4, hr_res // 4)
+        np.random.seed(seed)
+        if name in ("ag", "pad", "frames3"):
+            sig = {"ag": 13, "pad": 13, "frames3": 5}[name]
+            out[f"{name}_noise"] = np.random.normal(0, sig, lr_shape)
+        elif name == "ag_gain":
+            out[f"{name}_noise"] = np.random.normal(-3, 7.5, lr_shape)
+    np.savez_compressed(OUT / "pairs.npz", **out)
+
+
+def gen_model(pssr):
+    from pssr.models._blocks import Reconstruction, ResBlock
+    from pssr.models.resunet import ResUNet
+    out = {}
+    cfgs = {
+        "tiny": dict(channels=1, hidden=[16, 32, 64], scale=4, depth=3, hw=32, n=2),
+        "d1s2": dict(channels=[3, 1], hidden=[16, 32], scale=2, depth=1, hw=16, n=3),
+        "c33": dict(channels=[3, 3], hidden=[8, 16, 32, 64], scale=4, depth=0, hw=32, n=1),
+    }
+    for name, cfg in cfgs.items():
+        torch.manual_seed(7)
+        hw, n = cfg.pop("hw"), cfg.pop("n")
+        model = ResUNet(**cfg)
+        cin = model.norm.num_features
+        # non-trivial BN state so eval mode is a real test
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+                    m.running_mean.uniform_(-0.1, 0.1), m.running_var.uniform_(0.5, 1.5)
+        x = torch.rand(n, cin, hw, hw) * 255
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            y_eval = model(x)
+        model.train()
+        y_train = model(x)
+        target = torch.rand_like(y_train) * 255
+        loss = torch.nn.functional.mse_loss(y_train / 255, target / 255)
+        loss.backward()
+        out[f"{name}_cfg"] = np.array([n, cin, hw, cfg["scale"], cfg["depth"], len(cfg["hidden"]), y_eval.shape[1]])
+        out[f"{name}_hidden"] = np.array(cfg["hidden"])
+        out[f"{name}_x"] = x.numpy()
+        out[f"{name}_target"] = target.numpy()
+        out[f"{name}_y_eval"] = y_eval.numpy()
+        out[f"{name}_y_train"] = y_train.detach().numpy()
+        out[f"{name}_loss"] = np.array(loss.item())
+        for k, v in sd0.items():
+            out[f"{name}_sd/{k}"] = v.numpy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"{name}_sd_after/{k}"] = v.numpy()
+        for k, p in model.named_parameters():
+            out[f"{name}_grad/{k}"] = p.grad.numpy()
+    # per-block fixtures
+    torch.manual_seed(3)
+    rb = ResBlock(8, 16, 3).train()
+    x = torch.randn(2, 8, 12, 12)
+    y = rb(x)
+    out["resblock_x"], out["resblock_y"] = x.numpy(), y.detach().numpy()
+    for k, v in rb.state_dict().items():
+        out[f"resblock_sd/{k}"] = v.numpy()
+    rec = Reconstruction(1, 1, 8, 4)
+    x = torch.randn(2, 9, 8, 8)
+    out["recon_x"], out["recon_y"] = x.numpy(), rec(x).detach().numpy()
+    for k, v in rec.state_dict().items():
+        out[f"recon_sd/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "model.npz", **out)
+
+
+def gen_init(pssr):
+    """Pins that constructing the build's ResUNet under the same torch seed reproduces the
+    reference's default initialisation (parameter creation order and shapes)."""
+    from pssr.models.resunet import ResUNet
+    out = {}
+    for name, kw in {"default_small": dict(hidden=[8, 16, 32]), "c31": dict(channels=[3, 1], hidden=[8, 16], depth=1, scale=2)}.items():
+        torch.manual_seed(1234)
+        m = ResUNet(**kw)
+        sd = m.state_dict()
+        out[f"{name}_keys"] = np.array(list(sd.keys()))
+        out[f"{name}_sums"] = np.array([float(v.double().sum()) for v in sd.values()])
+        out[f"{name}_abssums"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    torch.manual_seed(1234)
+    m = ResUNet()
+    sd = m.state_dict()
+    out["default_keys"] = np.array(list(sd.keys()))
+    out["default_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+    out["default_nparams"] = np.array(sum(p.numel() for p in m.parameters()))
+    out["default_repr"] = np.array(m.extra_repr())
+    np.savez_compressed(OUT / "init.npz", **out)
+
+
+def gen_loss(pssr):
+    from pssr.util import SSIMLoss, _psnr_metric, pixel_metric
+    out = {}
+
+    class _One(torch.nn.Module):           # stands in for the absent pytorch_msssim module only
+        def forward(self, a, b):
+            return torch.tensor(1.0)
+
+    torch.manual_seed(9)
+    for i, (n, hw) in enumerate([(2, 48), (1, 200), (3, 17)]):
+        x, y = torch.rand(n, 1, hw, hw), torch.rand(n, 1, hw, hw)
+        x.requires_grad_(True)
+        lf = SSIMLoss(channels=1, mix=0.0)
+        lf.ssim = _One()                   # mix=0 => loss == the Gaussian-L1 term exactly
+        val = lf(x, y)
+        val.backward()
+        out[f"l1_{i}_x"], out[f"l1_{i}_y"] = x.detach().numpy(), y.numpy()
+        out[f"l1_{i}_val"], out[f"l1_{i}_grad"] = np.array(val.item()), x.grad.numpy()
+    out["psnr_0p01"] = np.array(float(_psnr_metric(torch.tensor(0.01))))
+    out["pixel_0p01"] = np.array(pixel_metric(0.01))
+    np.savez_compressed(OUT / "loss_l1.npz", **out)
+
+
+def gen_post(pssr):
+    from pssr.data import _get_val_idx, _invert_idx, _n_tiles, _sliding_window
+    from pssr.predict import _pred_array
+    from pssr.util import _patch_images
+    rng = np.random.default_rng(21)
+    out = {}
+    x = np.concatenate([np.array([-3.2, 0.4, 254.6, 300.0, 254.999, 255.0, 0.999, -0.0, 127.5]),
+                        rng.uniform(-20, 280, 247)]).astype(np.float32).reshape(1, 1, 16, 16)
+    out["pred_in"], out["pred_out"] = x, _pred_array(torch.tensor(x))
+    tiles = rng.integers(0, 256, size=(12, 32, 32)).astype(np.uint8)
+    for name, (ov, mg) in {"a": (8, 0), "b": (8, 3), "c": (0, 0)}.items():
+        out[f"patch_{name}"] = _patch_images(tiles, 4, 3, ov, mg)
+        out[f"patch_{name}_args"] = np.array([4, 3, ov, mg])
+    out["patch_tiles"] = tiles
+    sheet = rng.integers(0, 256, size=(1, 100, 90)).astype(np.uint8)
+    out["sheet"] = sheet
+    out["ntiles"] = np.array(_n_tiles(sheet, 32, 24))
+    out["tile5"] = _sliding_window(sheet, 32, 24, None, 1, 5, False)
+    out["ntiles_4096"] = np.array(_n_tiles(np.zeros((1, 4096, 4096), np.uint8), 128, 96))
+    out["val_10_0p1"] = np.array(_get_val_idx([1] * 10, 0.1, 0))
+    out["val_10_0p3"] = np.array(_get_val_idx([1] * 10, 0.3, 0))
+    out["val_slices"] = np.array(_get_val_idx([2, 3, 1, 4], 0.5, 3))
+    out["inv_10"] = _invert_idx([0, 3, 5], 10)
+    np.savez_compressed(OUT / "post.npz", **out)
+
+
+def gen_train_trace(pssr):
+    """2-epoch train_paired trace on an in-memory dataset (MSELoss): pins step order,
+    train/eval toggling, log cadence and the returned loss lists (pssr/train.py:19-166)."""
+    import pssr.train as T
+    from pssr.models.resunet import ResUNet
+
+    T.ssim = lambda a, b, data_range=255: torch.tensor(0.0)     # absent third-party metric (log line only)
+    rng = np.random.default_rng(77)
+    hrs = rng.integers(0, 256, size=(6, 1, 32, 32)).astype(np.float32)
+    lrs = np.stack([h.reshape(1, 8, 4, 8, 4).mean((2, 4)) for h in hrs]).astype(np.float32)
+
+    class DS(torch.utils.data.Dataset):
+        val_idx, extra_hr_files, crop_res, lr_scale = [4, 5], None, 32, 4
+
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return torch.tensor(hrs[i]), torch.tensor(lrs[i])
+
+    torch.manual_seed(5)
+    random.seed(5)
+    np.random.seed(5)
+    model = ResUNet(hidden=[8, 16], depth=1)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    random.seed(6)
+    tl, vl = T.train_paired(model, DS(), 2, torch.nn.MSELoss(), opt, epochs=2, log_frequency=1)
+    out = {"hrs": hrs, "lrs": lrs, "train_losses": np.array(tl), "val_losses": np.array(vl)}
+    for k, v in sd0.items():
+        out[f"sd0/{k}"] = v.numpy()
+    for k, v in model.state_dict().items():
+        out[f"sd1/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "train_trace.npz", **out)
+
+
+if __name__ == "__main__":
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(1)   # deterministic summation order for the fixtures
+    pssr = import_reference()
+    for fn in (gen_bilinear, gen_pairs, gen_model, gen_init, gen_loss, gen_post, gen_train_trace):
+        fn(pssr)
+        print("wrote", fn.__name__)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size // 1024, "KiB")

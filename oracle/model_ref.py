@@ -1,0 +1,124 @@
+"""Oracle: ResUNet forward as a pure function of a reference-format ``state_dict``.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  torch-CPU fp32, autograd-capable so the
+same function is the oracle for the backward pass (gradients of every tensor in ``params``).
+
+Follows, as a restatement (nothing imported from the reference):
+  * pssr/models/resunet.py:65-96   (ResUNet.forward: scale, norm, encoder, pool, shuffle, cat, head)
+  * pssr/models/_blocks.py:20-41   (ResBlock: [conv3x3, BN, ReLU]*depth + conv3x3, BN ; + conv1x1 ; ReLU)
+  * pssr/models/_blocks.py:6-18    (Reconstruction: conv3x3 -> ReLU -> pixel_shuffle(scale) -> conv3x3)
+State-dict key names are the reference's (SURVEY.md §8b "Checkpoint compatibility").
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # torch.nn.BatchNorm2d default used by pssr/models/_blocks.py:31
+BN_MOMENTUM = 0.1
+
+
+def _bn(x, sd, prefix, train, new_stats):
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if train:
+        # batch statistics over N,H,W; running stats updated with momentum .1 and the
+        # unbiased variance (torch semantics)
+        rm2, rv2 = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, True, BN_MOMENTUM, BN_EPS)
+        new_stats[prefix + ".running_mean"] = rm2
+        new_stats[prefix + ".running_var"] = rv2
+        return y
+    return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+
+
+def resblock_forward(x, sd, prefix, depth, train, new_stats):
+    """pssr/models/_blocks.py:39-41 with the Sequential laid out as at :26-33."""
+    n_layers = max(depth, 0) + 1
+    h = x
+    for i in range(n_layers):
+        h = F.conv2d(h, sd[f"{prefix}.conv.{3 * i}.weight"], sd[f"{prefix}.conv.{3 * i}.bias"], padding=1)
+        h = _bn(h, sd, f"{prefix}.conv.{3 * i + 1}", train, new_stats)
+        if i + 1 < n_layers:
+            h = F.relu(h)
+    r = F.conv2d(x, sd[f"{prefix}.respass.weight"], sd[f"{prefix}.respass.bias"])
+    return F.relu(h + r)
+
+
+def reconstruction_forward(x, sd, prefix, scale):
+    """pssr/models/_blocks.py:15-18."""
+    x = F.relu(F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1))
+    x = F.pixel_shuffle(x, scale)
+    return F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], padding=1)
+
+
+def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False):
+    """ResUNet.forward (pssr/models/resunet.py:65-96), non-atrous, no PSP pooling.
+
+    ``x``: float32 [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats).
+    """
+    new_stats: dict[str, torch.Tensor] = {}
+    x = x / 128 - 1
+    x = _bn(x, sd, "norm", train, new_stats)
+    skips = [x]
+    for i in range(n_levels):
+        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats)
+        if i + 1 < n_levels:
+            skips.append(x)
+            x = F.max_pool2d(x, kernel_size=2)
+    for j in range(n_levels - 1):
+        x = F.pixel_shuffle(x, 2)
+        x = torch.cat([x, skips.pop()], dim=1)
+        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats)
+    x = torch.cat([x, skips.pop()], dim=1)
+    assert not skips
+    x = reconstruction_forward(x, sd, "reconstruction", scale)
+    return x * 128 + 128, new_stats
+
+
+def make_state_dict(channels=(1, 1), hidden=(64, 128, 256, 512, 1024), scale=4, depth=3, seed=0,
+                    randomize_bn=True):
+    """Seeded random reference-format state_dict (shapes as pssr/models/resunet.py:50-63).
+
+    Used where a fixture-sized model is needed without the reference (GPU box).  Weight
+    scale ~ kaiming-uniform like torch's Conv2d default so activations stay O(1).
+    """
+    g = torch.Generator().manual_seed(seed)
+    cin, cout = channels
+    sd = {}
+
+    def conv(prefix, co, ci, k):
+        bound = 1.0 / (ci * k * k) ** 0.5
+        sd[prefix + ".weight"] = (torch.rand(co, ci, k, k, generator=g) * 2 - 1) * bound
+        sd[prefix + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    def bn(prefix, c):
+        if randomize_bn:
+            sd[prefix + ".weight"] = 0.5 + torch.rand(c, generator=g)
+            sd[prefix + ".bias"] = (torch.rand(c, generator=g) - 0.5) * 0.4
+            sd[prefix + ".running_mean"] = (torch.rand(c, generator=g) - 0.5) * 0.2
+            sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        else:
+            sd[prefix + ".weight"] = torch.ones(c)
+            sd[prefix + ".bias"] = torch.zeros(c)
+            sd[prefix + ".running_mean"] = torch.zeros(c)
+            sd[prefix + ".running_var"] = torch.ones(c)
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def block(prefix, ci, co):
+        n_layers = max(depth, 0) + 1
+        for i in range(n_layers):
+            conv(f"{prefix}.conv.{3 * i}", co, ci if i == 0 else co, 3)
+            bn(f"{prefix}.conv.{3 * i + 1}", co)
+        conv(f"{prefix}.respass", co, ci, 1)
+
+    bn("norm", cin)
+    layers = [cin, *hidden]
+    n = len(hidden)
+    for i in range(n):
+        block(f"encoder.{i}", layers[i], layers[i + 1])
+        if i + 1 < n:
+            block(f"decoder.{i}", layers[-i - 1] - int(layers[-i - 2] / 2), layers[-i - 2])
+    conv("reconstruction.pre", scale * scale * hidden[0], hidden[0] + cin, 3)
+    conv("reconstruction.conv", cout, hidden[0], 3)
+    return sd
