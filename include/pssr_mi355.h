@@ -1,0 +1,106 @@
+/* pssr_mi355.h — C ABI of libpssr_mi355.so, the MI355X (gfx950) kernels behind pssr2_amd.
+ *
+ * The reference (ucsdmanorlab/PSSR2) is pure Python and has no FFI layer; its hot path is the
+ * torch.nn ops listed in SURVEY.md §8a.  Each entry point below replaces one (or a fused group) of
+ * those ops; the reference file:line it stands for is cited next to it.  Conventions:
+ *   - every pointer is a DEVICE pointer unless marked "host"; the caller owns all memory,
+ *     the library allocates nothing persistent;
+ *   - every call takes the HIP stream to launch on (pssr_stream_t == hipStream_t) and never
+ *     synchronises it;
+ *   - return value: 0 on success, a negative PSSR_ERR_* otherwise (never throws across the ABI);
+ *     pssr_last_error() returns a thread-local message for the last failure;
+ *   - activations are NHWC ("pixel-major") with an explicit channel stride so that an op can read
+ *     or write a channel slice of a wider buffer (this is how torch.cat is elided);
+ *   - dtype of activations / packed weights: PSSR_F32 (exact-f32 MFMA path, parity) or
+ *     PSSR_BF16 (bf16 storage, f32 accumulate).  Parameters, statistics and gradients are f32/f64.
+ */
+#ifndef PSSR_MI355_H
+#define PSSR_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pssr_stream_t; /* hipStream_t */
+
+enum { PSSR_F32 = 0, PSSR_BF16 = 1 };
+
+enum {
+    PSSR_OK = 0,
+    PSSR_ERR_ARG = -1,     /* invalid shape / alignment / enum */
+    PSSR_ERR_LAUNCH = -2,  /* HIP launch failure */
+    PSSR_ERR_UNSUPPORTED = -3
+};
+
+int pssr_abi_version(void);
+const char* pssr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  torch keeps Conv2d weights OIHW f32 (pssr/models/_blocks.py:10-11,28,35); the
+ * conv kernels consume a K-chunked, LDS-image-ordered copy in the compute dtype:
+ *   packed[chunk][tap][n (padded to 128)][32 bytes = 2 swizzled 16-byte slots of K]
+ * mode 0 (forward):  GEMM-K = input channels  [ci_begin, ci_begin+ci_count) of the OIHW tensor,
+ *                    GEMM-N = output channels (optionally permuted by `n_perm`: n_src = n_perm[n]).
+ * mode 1 (dgrad):    GEMM-K = output channels, GEMM-N = input channels of the range, taps flipped.
+ * mode 2 (flat-K):   a KxK conv seen as 1x1 over im2col'ed channels: K index = (ci-ci_begin)*ks*ks + tap.
+ * `k_pad` = GEMM-K rounded up to 16, `n_pad` = GEMM-N rounded up to 128 (zero filled).
+ */
+int pssr_pack_conv_weight(const float* w_oihw, void* packed, int cout, int cin, int ks,
+                          int ci_begin, int ci_count, int mode, const int32_t* n_perm,
+                          int k_pad, int n_pad, int dtype, pssr_stream_t stream);
+/* bytes needed for a packed weight */
+int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int dtype);
+
+/* Inverse of mode 0 / mode 2 for gradients: wgrad writes dW as f32 [n][tap][k_pad]; this scatters
+ * (adds when `accumulate`) into the OIHW f32 gradient of the parameter. */
+int pssr_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int cout, int cin, int ks,
+                           int ci_begin, int ci_count, int mode, const int32_t* n_perm,
+                           int k_pad, int accumulate, pssr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, stride 1, "same" zero padding, NHWC, MFMA 32x32 tiles.
+ * Replaces nn.Conv2d forward (pssr/models/_blocks.py:16-17,39-40) and, with mode-1 packed
+ * weights, its input-gradient; BatchNorm2d+ReLU of the *previous* layer is applied while the
+ * input tile is staged (prologue), and BatchNorm statistics / residual tail / ReLU-mask are
+ * applied while the output tile is written (epilogue), so no normalised tensor is materialised.
+ */
+enum { PSSR_PRO_NONE = 0, PSSR_PRO_BN_RELU = 1 };
+enum {
+    PSSR_EPI_STORE = 0,      /* out = acc + bias                                             */
+    PSSR_EPI_TAIL = 1,       /* out = relu(acc + bias + aux*aux_scale + aux_shift)  (ResBlock tail, _blocks.py:40) */
+    PSSR_EPI_DGRAD_MASK = 2  /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
+};
+enum {
+    PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
+    PSSR_FLAG_STATS = 2   /* accumulate per-channel f64 sums into `stats`:
+                             EPI_STORE: [sum v, sum v^2]; EPI_DGRAD_MASK: [sum g, sum g*xhat] */
+};
+
+typedef struct pssr_conv_desc {
+    int32_t dtype;
+    int32_t n, h, w;            /* batch and spatial size (input == output)                    */
+    /* up to two input sources accumulated into one output; source 1 is optional (cin1 == 0)    */
+    const void* in0; int32_t in0_cstride, in0_coff, cin0, taps0;   /* taps: 9 (3x3) or 1 (1x1)  */
+    const void* w0;             /* packed (pssr_pack_conv_weight), K padded to 16               */
+    const void* in1; int32_t in1_cstride, in1_coff, cin1, taps1;
+    const void* w1;
+    int32_t prologue;           /* applies to source 0 only                                    */
+    const float* pro_scale;     /* [cin0] gamma*invstd                                         */
+    const float* pro_shift;     /* [cin0] beta - mean*gamma*invstd                             */
+    void* out; int32_t out_cstride, out_coff, cout, n_pad;
+    const float* bias;          /* [cout] or NULL                                              */
+    int32_t epilogue, flags;
+    const void* aux; int32_t aux_cstride, aux_coff;
+    const float* aux_scale; const float* aux_shift;      /* [cout]                              */
+    const float* aux_mean; const float* aux_invstd;      /* [cout] (DGRAD_MASK + STATS)         */
+    double* stats;              /* [2*cout], caller-zeroed                                     */
+} pssr_conv_desc;
+
+int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSSR_MI355_H */

@@ -1,0 +1,66 @@
+"""ctypes binding of libpssr_mi355.so (the C ABI declared in include/pssr_mi355.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol is absent this
+module raises at first use, and every op raises ``RuntimeError`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libpssr_mi355.so"
+_lib = None
+
+F32, BF16 = 0, 1
+PRO_NONE, PRO_BN_RELU = 0, 1
+EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK = 0, 1, 2
+FLAG_RELU, FLAG_STATS = 1, 2
+
+c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    """struct pssr_conv_desc (include/pssr_mi355.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("in0", c_void_p), ("in0_cstride", C.c_int32), ("in0_coff", C.c_int32), ("cin0", C.c_int32), ("taps0", C.c_int32),
+        ("w0", c_void_p),
+        ("in1", c_void_p), ("in1_cstride", C.c_int32), ("in1_coff", C.c_int32), ("cin1", C.c_int32), ("taps1", C.c_int32),
+        ("w1", c_void_p),
+        ("prologue", C.c_int32), ("pro_scale", c_void_p), ("pro_shift", c_void_p),
+        ("out", c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("cout", C.c_int32), ("n_pad", C.c_int32),
+        ("bias", c_void_p),
+        ("epilogue", C.c_int32), ("flags", C.c_int32),
+        ("aux", c_void_p), ("aux_cstride", C.c_int32), ("aux_coff", C.c_int32),
+        ("aux_scale", c_void_p), ("aux_shift", c_void_p), ("aux_mean", c_void_p), ("aux_invstd", c_void_p),
+        ("stats", c_void_p),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C pssr2_amd/csrc). pssr2_amd has no CPU fallback.")
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.pssr_last_error.restype = C.c_char_p
+        _lib.pssr_packed_weight_bytes.restype = C.c_int64
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {lib().pssr_last_error().decode()}")
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

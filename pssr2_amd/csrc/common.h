@@ -1,0 +1,96 @@
+// Shared device helpers for the pssr2_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pssr_mi355.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// A "slot" is 16 bytes of consecutive channels of one pixel: 8 bf16 or 4 f32.  Every tile in
+// LDS is made of 32-byte rows (2 slots) so that the bf16 and f32 builds share one byte geometry.
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int EPS = 4;      // elements per slot
+    static constexpr int KCH = 8;      // channels per K-chunk (2 slots)
+    typedef f32x4 frag_t;
+    static __device__ __forceinline__ void unpack(const uint4& raw, float* f) {
+        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+        f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+    static __device__ __forceinline__ float round(float v) { return v; }
+    // 32x32 tile, K = one slot per lane half: 4 x v_mfma_f32_32x32x2_f32 (exact f32 fma chain)
+    static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+template <> struct TT<bf16_t> {
+    static constexpr int EPS = 8;
+    static constexpr int KCH = 16;
+    typedef bf16x8 frag_t;
+    static __device__ __forceinline__ void unpack(const uint4& raw, float* f) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        union { bf16x8 v; uint4 u; } cv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cv.v[i] = (bf16_t)f[i];
+        return cv.u;
+    }
+    static __device__ __forceinline__ float round(float v) { return (float)(bf16_t)v; }
+    // one v_mfma_f32_32x32x16_bf16
+    static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
+        union { uint4 u; bf16x8 v; } ca, cb;
+        ca.u = a; cb.u = b;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca.v, cb.v, c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// store 4 consecutive channels
+__device__ __forceinline__ void store4(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(bf16_t* p, const float* v) {
+    union { bf16x4 v; uint2 u; } cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv.v[i] = (bf16_t)v[i];
+    *(uint2*)p = cv.u;
+}
+__device__ __forceinline__ void load4(const float* p, float* v) {
+    float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float* v) {
+    uint2 t = *(const uint2*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+// status helpers for the C ABI
+void pssr_set_error(const char* fmt, ...);
+#define PSSR_CHECK(cond, code, ...)                         \
+    do {                                                    \
+        if (!(cond)) { pssr_set_error(__VA_ARGS__); return (code); } \
+    } while (0)
+#define PSSR_LAUNCH_CHECK()                                                          \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) { pssr_set_error("launch failed: %s", hipGetErrorString(e__)); return PSSR_ERR_LAUNCH; } \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

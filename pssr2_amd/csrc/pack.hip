@@ -1,0 +1,98 @@
+// Weight packing (OIHW f32 -> K-chunked LDS-image order in the compute dtype) and the inverse
+// scatter for weight gradients.  Pure data movement: one thread per packed element.
+#include "common.h"
+
+namespace {
+
+// Maps a packed position (chunk, tap, n, slotpos, e) to the source OIHW element, or -1 for padding.
+struct PackMap {
+    int cout, cin, ks, ci_begin, ci_count, mode, taps;
+    const int32_t* n_perm;
+    __device__ __forceinline__ long src_index(int k, int tap, int n) const {
+        // k: GEMM-K index (un-padded range checked by caller), n: GEMM-N index
+        const int kk = ks * ks;
+        if (mode == 0) {          // forward: K = ci, N = co
+            if (k >= ci_count || n >= cout) return -1;
+            const int co = n_perm ? n_perm[n] : n;
+            return ((long)co * cin + ci_begin + k) * kk + tap;
+        } else if (mode == 1) {   // dgrad: K = co, N = ci, taps flipped
+            if (k >= cout || n >= ci_count) return -1;
+            const int co = n_perm ? n_perm[k] : k;
+            return ((long)co * cin + ci_begin + n) * kk + (kk - 1 - tap);
+        } else {                  // flat-K: K = (ci - ci_begin)*kk + tap', single tap
+            if (k >= ci_count * kk || n >= cout) return -1;
+            const int co = n_perm ? n_perm[n] : n;
+            return ((long)co * cin + ci_begin) * kk + k;
+        }
+    }
+};
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed, PackMap m, int k_pad, int n_pad, long total) {
+    constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = i % EPS;
+        long t = i / EPS;
+        const int slotpos = t % 2; t /= 2;
+        const int n = t % n_pad; t /= n_pad;
+        const int tap = t % m.taps;
+        const int chunk = t / m.taps;
+        const int slot = slotpos ^ ((n >> 3) & 1);
+        const int k = chunk * KCH + slot * EPS + e;
+        const long s = m.src_index(k, tap, n);
+        packed[i] = s >= 0 ? (T)w[s] : (T)0.f;
+    }
+}
+
+// dW packed layout produced by the wgrad kernel: f32 [n][tap][k_pad]
+__global__ void unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, PackMap m, int k_pad, int accumulate, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % k_pad;
+        long t = i / k_pad;
+        const int tap = t % m.taps;
+        const int n = t / m.taps;
+        const long s = m.src_index(k, tap, n);
+        if (s >= 0) dw[s] = accumulate ? dw[s] + dwp[i] : dwp[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int dtype) {
+    return (int64_t)taps * k_pad * n_pad * (dtype == PSSR_BF16 ? 2 : 4);
+}
+
+extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int cin, int ks, int ci_begin, int ci_count,
+                                     int mode, const int32_t* n_perm, int k_pad, int n_pad, int dtype, pssr_stream_t stream) {
+    PSSR_CHECK(w && packed, PSSR_ERR_ARG, "pack: null pointer");
+    PSSR_CHECK(ks == 1 || ks == 3, PSSR_ERR_ARG, "pack: ks=%d", ks);
+    PSSR_CHECK(mode >= 0 && mode <= 2, PSSR_ERR_ARG, "pack: mode=%d", mode);
+    PSSR_CHECK(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= cin, PSSR_ERR_ARG, "pack: channel range");
+    PSSR_CHECK(k_pad % 16 == 0 && n_pad % 128 == 0, PSSR_ERR_ARG, "pack: k_pad=%d n_pad=%d", k_pad, n_pad);
+    const int gk = mode == 0 ? ci_count : mode == 1 ? cout : ci_count * ks * ks;
+    const int gn = mode == 1 ? ci_count : cout;
+    PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode == 2 ? 1 : ks * ks, n_perm};
+    const long total = (long)m.taps * k_pad * n_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == PSSR_BF16)
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, m, k_pad, n_pad, total);
+    else if (dtype == PSSR_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, m, k_pad, n_pad, total);
+    else
+        PSSR_CHECK(false, PSSR_ERR_ARG, "pack: dtype=%d", dtype);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+extern "C" int pssr_unpack_conv_wgrad(const float* dwp, float* dw, int cout, int cin, int ks, int ci_begin, int ci_count,
+                                      int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
+    PSSR_CHECK(dwp && dw, PSSR_ERR_ARG, "unpack: null pointer");
+    PSSR_CHECK(mode == 0 || mode == 2, PSSR_ERR_ARG, "unpack: mode=%d", mode);
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode == 2 ? 1 : ks * ks, n_perm};
+    const long total = (long)cout * m.taps * k_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwp, dw, m, k_pad, accumulate, total);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}

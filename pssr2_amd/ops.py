@@ -1,0 +1,77 @@
+"""Thin Python wrappers over the C ABI (one function per entry point of include/pssr_mi355.h).
+
+Tensors are only carriers of device memory here: every wrapper passes raw pointers, sizes and the
+current HIP stream to libpssr_mi355.so.  Nothing in this module computes with torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return L.F32
+    if dt == torch.bfloat16:
+        return L.BF16
+    raise ValueError(f"unsupported compute dtype {dt}; use torch.float32 or torch.bfloat16")
+
+
+def pad_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class PackedWeight:
+    """A conv weight in the kernel's K-chunked layout plus the GEMM dims it was packed with."""
+    __slots__ = ("data", "taps", "k_pad", "n_pad", "dtype")
+
+    def __init__(self, data, taps, k_pad, n_pad, dtype):
+        self.data, self.taps, self.k_pad, self.n_pad, self.dtype = data, taps, k_pad, n_pad, dtype
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: int, mode: int = 0, ci_begin: int = 0, ci_count: int | None = None,
+                     n_perm: torch.Tensor | None = None, out: PackedWeight | None = None) -> PackedWeight:
+    """OIHW f32 -> packed (mode 0 forward, 1 dgrad, 2 flat-K im2col)."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
+    cout, cin, ks, _ = w.shape
+    ci_count = cin - ci_begin if ci_count is None else ci_count
+    gk = ci_count if mode == 0 else cout if mode == 1 else ci_count * ks * ks
+    gn = ci_count if mode == 1 else cout
+    taps = 1 if mode == 2 else ks * ks
+    k_pad, n_pad = pad_to(gk, 16), pad_to(gn, 128)
+    if out is None:
+        nbytes = L.lib().pssr_packed_weight_bytes(taps, k_pad, n_pad, dtype)
+        out = PackedWeight(torch.empty(nbytes, dtype=torch.uint8, device=w.device), taps, k_pad, n_pad, dtype)
+    L.check(L.lib().pssr_pack_conv_weight(L.ptr(w), L.ptr(out.data), cout, cin, ks, ci_begin, ci_count, mode,
+                                          L.ptr(n_perm), k_pad, n_pad, dtype, L.stream_ptr()), "pssr_pack_conv_weight")
+    return out
+
+
+def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_coff=0, bias=None,
+           x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
+           pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
+           aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None):
+    """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff)."""
+    d = L.ConvDesc()
+    d.dtype = w0.dtype
+    d.n, d.h, d.w = n, h, w
+    d.in0, d.in0_cstride, d.in0_coff, d.cin0, d.taps0, d.w0 = L.ptr(x), x.shape[-1], in0_coff, cin0, w0.taps, L.ptr(w0.data)
+    if w1 is not None:
+        d.in1, d.in1_cstride, d.in1_coff, d.cin1, d.taps1, d.w1 = L.ptr(x1), x1.shape[-1], in1_coff, cin1, w1.taps, L.ptr(w1.data)
+        assert w1.n_pad == w0.n_pad and w1.dtype == w0.dtype
+    d.prologue = L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
+    d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
+    d.out, d.out_cstride, d.out_coff, d.cout, d.n_pad = L.ptr(out), out.shape[-1], out_coff, cout, w0.n_pad
+    d.bias = L.ptr(bias)
+    d.epilogue, d.flags = epilogue, flags
+    if aux is not None:
+        d.aux, d.aux_cstride, d.aux_coff = L.ptr(aux), aux.shape[-1], aux_coff
+    d.aux_scale, d.aux_shift, d.aux_mean, d.aux_invstd = L.ptr(aux_scale), L.ptr(aux_shift), L.ptr(aux_mean), L.ptr(aux_invstd)
+    d.stats = L.ptr(stats)
+    L.check(L.lib().pssr_conv2d(C.byref(d), L.stream_ptr()), "pssr_conv2d")
+    return out

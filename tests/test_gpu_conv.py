@@ -1,0 +1,157 @@
+"""HIP implicit-GEMM conv (through the C ABI) vs torch-CPU fp32 F.conv2d on the same inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x, cpad, dt):
+    n, c, h, w = x.shape
+    out = torch.zeros(n, h, w, cpad, dtype=dt, device="cuda")
+    out[..., :c] = x.permute(0, 2, 3, 1).to("cuda").to(dt)
+    return out
+
+
+def _tol(dt, k):
+    return (2e-5 * max(1, k) ** 0.5, 1e-5) if dt == torch.float32 else (2.5e-2, 2e-2)
+
+
+CASES = [
+    # n, cin, cout, h, w, ks
+    (2, 16, 64, 16, 16, 3),
+    (1, 32, 128, 24, 40, 3),     # partial tiles in both directions
+    (3, 48, 16, 8, 8, 3),        # GEO 1 (2 images / tile), odd batch
+    (9, 16, 32, 4, 4, 3),        # GEO 2
+    (33, 16, 8, 2, 2, 3),        # GEO 3
+    (130, 32, 36, 1, 1, 3),      # GEO 4
+    (2, 64, 256, 16, 16, 1),     # 1x1
+    (2, 80, 12, 12, 20, 3),      # cout not multiple of 32
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_and_dgrad(case, dt):
+    from pssr2_amd import ops, _lib as L
+    n, cin, cout, h, w, ks = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g)
+    code = ops.dtype_code(dt)
+    xq = x.to(dt).float()
+    wq = wt.to(dt).float()
+    ref = F.conv2d(xq, wq, b, padding=ks // 2)
+
+    cpad = ops.pad_to(cin, 16)
+    xd = _nhwc(x, cpad + 16, dt)              # slice of a wider buffer: channel offset 16
+    xd = torch.cat([torch.full_like(xd[..., :16], 7.0), xd[..., :cpad]], -1).contiguous()
+    pw = ops.pack_conv_weight(wt.cuda(), code, mode=0)
+    out = torch.full((n, h, w, cout + 8), -5.0, dtype=dt, device="cuda")
+    ops.conv2d(xd, cpad, pw, out, cout, n=n, h=h, w=w, in0_coff=16, out_coff=4, bias=b.cuda())
+    torch.cuda.synchronize()
+    got = out[..., 4:4 + cout].float().cpu().permute(0, 3, 1, 2)
+    rtol, atol = _tol(dt, cin * ks * ks)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rtol, atol=atol * ref.abs().max().item())
+    assert (out[..., :4] == -5).all() and (out[..., 4 + cout:] == -5).all()
+
+    # input gradient: mode-1 weights, GEMM-K = cout, GEMM-N = cin
+    dy = torch.randn(n, cout, h, w, generator=g)
+    dyq = dy.to(dt).float()
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wq, dyq, padding=ks // 2)
+    pwd = ops.pack_conv_weight(wt.cuda(), code, mode=1)
+    dyd = _nhwc(dy, ops.pad_to(cout, 16), dt)
+    cin4 = ops.pad_to(cin, 4)
+    dx = torch.zeros(n, h, w, cin4, dtype=dt, device="cuda")
+    ops.conv2d(dyd, ops.pad_to(cout, 16), pwd, dx, cin4, n=n, h=h, w=w)
+    torch.cuda.synchronize()
+    got = dx[..., :cin].float().cpu().permute(0, 3, 1, 2)
+    rtol, atol = _tol(dt, cout * ks * ks)
+    np.testing.assert_allclose(got.numpy(), ref_dx.numpy(), rtol=rtol, atol=atol * ref_dx.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_fused_prologue_epilogues(dt):
+    from pssr2_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(3)
+    n, cin, cout, h, w = 2, 32, 64, 16, 24
+    code = ops.dtype_code(dt)
+    yprev = torch.randn(n, cin, h, w, generator=g)
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    yq = yprev.to(dt).float()
+    a = F.relu(yq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dt).float()
+    ref = F.conv2d(a, wt.to(dt).float(), b, padding=1)
+    refq = ref.to(dt).float()
+
+    xd = _nhwc(yprev, cin, dt)
+    pw = ops.pack_conv_weight(wt.cuda(), code)
+    out = torch.zeros(n, h, w, cout, dtype=dt, device="cuda")
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    ops.conv2d(xd, cin, pw, out, cout, n=n, h=h, w=w, bias=b.cuda(), pro_scale=scale.cuda(), pro_shift=shift.cuda(),
+               flags=L.FLAG_STATS, stats=stats)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    rtol, atol = _tol(dt, cin * 9)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rtol, atol=atol * ref.abs().max().item())
+    # statistics are those of the stored (rounded) values
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[:cout], got.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(s[cout:], (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
+
+    # tail epilogue: relu(conv1x1(x) + bias + aux*scale + shift)
+    w1 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    y4 = torch.randn(n, cout, h, w, generator=g)
+    s4, h4 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    x_in = torch.randn(n, cin, h, w, generator=g)
+    ref = F.relu(F.conv2d(x_in.to(dt).float(), w1.to(dt).float(), b) + y4.to(dt).float() * s4.view(1, -1, 1, 1) + h4.view(1, -1, 1, 1))
+    out2 = torch.zeros(n, h, w, cout, dtype=dt, device="cuda")
+    ops.conv2d(_nhwc(x_in, cin, dt), cin, ops.pack_conv_weight(w1.cuda(), code), out2, cout, n=n, h=h, w=w, bias=b.cuda(),
+               epilogue=L.EPI_TAIL, aux=_nhwc(y4, cout, dt), aux_scale=s4.cuda(), aux_shift=h4.cuda())
+    torch.cuda.synchronize()
+    got = out2.float().cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rtol, atol=atol * ref.abs().max().item())
+
+    # dgrad + relu mask + BN-backward statistics
+    dy = torch.randn(n, cout, h, w, generator=g)
+    mean, invstd = torch.randn(cin, generator=g) * 0.1, torch.rand(cin, generator=g) + 0.5
+    da = torch.nn.grad.conv2d_input(yprev.shape, wt.to(dt).float(), dy.to(dt).float(), padding=1)
+    mask = (yq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
+    gref = torch.where(mask, da, torch.zeros_like(da))
+    gd = torch.zeros(n, h, w, cin, dtype=dt, device="cuda")
+    st2 = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+    ops.conv2d(_nhwc(dy, cout, dt), cout, ops.pack_conv_weight(wt.cuda(), code, mode=1), gd, cin, n=n, h=h, w=w,
+               epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS, aux=xd, aux_scale=scale.cuda(), aux_shift=shift.cuda(),
+               aux_mean=mean.cuda(), aux_invstd=invstd.cuda(), stats=st2)
+    torch.cuda.synchronize()
+    got = gd.float().cpu().permute(0, 3, 1, 2)
+    rtol, atol = _tol(dt, cout * 9)
+    np.testing.assert_allclose(got.numpy(), gref.numpy(), rtol=rtol, atol=atol * gref.abs().max().item())
+    xhat = (yq - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    s = st2.cpu().numpy()
+    np.testing.assert_allclose(s[:cin], got.double().sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[cin:], (got.double() * xhat.double()).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=2e-3)
+
+
+def test_conv_two_sources_and_errors():
+    from pssr2_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(5)
+    n, h, w, c0, c1, cout = 2, 16, 16, 32, 1, 64
+    x0, x1 = torch.randn(n, c0, h, w, generator=g), torch.randn(n, c1, h, w, generator=g)
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(torch.cat([x0, x1], 1), wt, b, padding=1))
+    # source 1 = 3x3 neighbourhood of x1 unrolled into 9 (padded 16) channels, consumed as a flat-K 1x1 conv
+    col = F.unfold(x1, 3, padding=1).view(n, c1 * 9, h, w)
+    pw0 = ops.pack_conv_weight(wt.cuda(), L.F32, mode=0, ci_begin=0, ci_count=c0)
+    pw1 = ops.pack_conv_weight(wt.cuda(), L.F32, mode=2, ci_begin=c0, ci_count=c1)
+    out = torch.zeros(n, h, w, cout, device="cuda")
+    ops.conv2d(_nhwc(x0, c0, torch.float32), c0, pw0, out, cout, n=n, h=h, w=w, bias=b.cuda(),
+               x1=_nhwc(col, 16, torch.float32), cin1=16, w1=pw1, flags=L.FLAG_RELU)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+    with pytest.raises(RuntimeError, match="cin0"):
+        ops.conv2d(_nhwc(x0, c0, torch.float32), 24 + 1, pw0, out, cout, n=n, h=h, w=w)
