@@ -70,7 +70,9 @@ enum { PSSR_PRO_NONE = 0, PSSR_PRO_BN_RELU = 1 };
 enum {
     PSSR_EPI_STORE = 0,      /* out = acc + bias                                             */
     PSSR_EPI_TAIL = 1,       /* out = relu(acc + bias + aux*aux_scale + aux_shift)  (ResBlock tail, _blocks.py:40) */
-    PSSR_EPI_DGRAD_MASK = 2  /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
+    PSSR_EPI_DGRAD_MASK = 2, /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
+    PSSR_EPI_FINAL = 3       /* out_f32_nchw = (acc + bias)*out_scale + out_shift; any cout <= 32
+                                (Reconstruction.conv + "x*128+128", _blocks.py:17, resunet.py:95)  */
 };
 enum {
     PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
@@ -96,9 +98,29 @@ typedef struct pssr_conv_desc {
     const float* aux_scale; const float* aux_shift;      /* [cout]                              */
     const float* aux_mean; const float* aux_invstd;      /* [cout] (DGRAD_MASK + STATS)         */
     double* stats;              /* [2*cout], caller-zeroed                                     */
+    /* "blocked" pixel order (log2 r, 0 = plain NHWC): pixel (y,x) of an r-times upsampled image
+     * lives at ((y/r*W/r + x/r)*r*r + (y%r)*r + x%r), i.e. F.pixel_shuffle (_blocks.py:17) of an
+     * NHWC tensor whose channels were ordered sub-pixel-major needs no data movement at all.    */
+    int32_t in0_blk, out_blk, aux_blk;
+    float out_scale, out_shift; /* EPI_FINAL only                                              */
 } pssr_conv_desc;
 
 int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
+
+/* Weight gradient of the same convolution (autograd of nn.Conv2d.weight):
+ *   dw[n][tap][k] += sum_pixels dy[p][n] * prologue(in)[p + tap][k]      (f32, atomically added;
+ * the caller zeroes `dw`, then scatters it to OIHW with pssr_unpack_conv_wgrad).                */
+typedef struct pssr_wgrad_desc {
+    int32_t dtype;
+    int32_t n, h, w;
+    const void* dy; int32_t dy_cstride, dy_coff, dy_blk, cout;   /* cout*elemsize % 16 == 0       */
+    const void* in; int32_t in_cstride, in_coff, in_blk, cin_pad; /* cin_pad % 16 == 0            */
+    int32_t taps;
+    int32_t prologue; const float* pro_scale; const float* pro_shift;
+    float* dw;                                                   /* [cout][taps][cin_pad]        */
+} pssr_wgrad_desc;
+
+int pssr_conv2d_wgrad(const pssr_wgrad_desc* desc, pssr_stream_t stream);
 
 #ifdef __cplusplus
 }

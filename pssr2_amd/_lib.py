@@ -14,7 +14,7 @@ _lib = None
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_BN_RELU = 0, 1
-EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK = 0, 1, 2
+EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL = 0, 1, 2, 3
 FLAG_RELU, FLAG_STATS = 1, 2
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -35,6 +35,20 @@ class ConvDesc(C.Structure):
         ("aux", c_void_p), ("aux_cstride", C.c_int32), ("aux_coff", C.c_int32),
         ("aux_scale", c_void_p), ("aux_shift", c_void_p), ("aux_mean", c_void_p), ("aux_invstd", c_void_p),
         ("stats", c_void_p),
+        ("in0_blk", C.c_int32), ("out_blk", C.c_int32), ("aux_blk", C.c_int32),
+        ("out_scale", C.c_float), ("out_shift", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """struct pssr_wgrad_desc (include/pssr_mi355.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("dy", c_void_p), ("dy_cstride", C.c_int32), ("dy_coff", C.c_int32), ("dy_blk", C.c_int32), ("cout", C.c_int32),
+        ("in_", c_void_p), ("in_cstride", C.c_int32), ("in_coff", C.c_int32), ("in_blk", C.c_int32), ("cin_pad", C.c_int32),
+        ("taps", C.c_int32),
+        ("prologue", C.c_int32), ("pro_scale", c_void_p), ("pro_shift", c_void_p),
+        ("dw", c_void_p),
     ]
 
 

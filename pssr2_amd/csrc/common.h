@@ -81,6 +81,14 @@ __device__ __forceinline__ void load4(const bf16_t* p, float* v) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+// Pixel linearisation: plain NHWC, or "blocked" order of an r-times (r = 1<<blk) upsampled image
+// (see pssr_conv_desc in include/pssr_mi355.h).
+__device__ __forceinline__ long pix_index(int gi, int gy, int gx, int H, int W, int blk) {
+    if (blk == 0) return ((long)gi * H + gy) * W + gx;
+    const int R = 1 << blk;
+    return ((((long)gi * (H >> blk) + (gy >> blk)) * (W >> blk) + (gx >> blk)) << (2 * blk)) + ((gy & (R - 1)) << blk) + (gx & (R - 1));
+}
+
 // status helpers for the C ABI
 void pssr_set_error(const char* fmt, ...);
 #define PSSR_CHECK(cond, code, ...)                         \

@@ -27,6 +27,8 @@ struct ConvArgs {
     const void* aux; int aux_cs, aux_co;
     const float* aux_scale; const float* aux_shift; const float* aux_mean; const float* aux_invstd;
     double* stats;
+    int in0_blk, out_blk, aux_blk;
+    float out_scale, out_shift;
 };
 
 template <int GEO> struct Geo;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
 
     // ---- per-thread staging descriptors for the input halo (same pixels for every chunk)
-    long a_pix[C::A_ITEMS];
+    long a_pix[C::A_ITEMS];   // source 0 (possibly blocked order); source 1 is always plain NHWC
     int a_lds[C::A_ITEMS];
     bool a_ok[C::A_ITEMS];
     int a_half[C::A_ITEMS];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
         const bool inb = (idx < 2 * C::HP) && gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         a_ok[it] = inb;
-        a_pix[it] = inb ? ((long)gi * p.H + gy) * p.W + gx : 0;
+        a_pix[it] = inb ? pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) : 0;
         a_lds[it] = (idx < 2 * C::HP) ? (pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
         a_half[it] = half;
     }
@@ -127,7 +129,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int it = 0; it < C::A_ITEMS; ++it) {
             a_reg[it] = make_uint4(0, 0, 0, 0);
-            if (a_ok[it]) a_reg[it] = *(const uint4*)(in + a_pix[it] * cs + co + a_half[it] * EPS);
+            if (a_ok[it]) {
+                long pix = a_pix[it];
+                if (s && p.in0_blk) {   // rare: recompute the plain index for source 1
+                    const int idx = tid + it * 256, pp = idx >> 1;
+                    const int img = pp / C::HPI, rem = pp % C::HPI;
+                    pix = ((long)(img0 + img) * p.H + (y0 + rem / C::HW2 - 1)) * p.W + (x0 + rem % C::HW2 - 1);
+                }
+                a_reg[it] = *(const uint4*)(in + pix * cs + co + a_half[it] * EPS);
+            }
         }
         const char* wsrc = (const char*)p.w[s] + ((long)chunk * taps * p.n_pad + n0) * 32;
 #pragma unroll
@@ -210,8 +220,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const bool n_ok = n_base < p.cout;
     float bias[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0}, xh[4] = {0, 0, 0, 0}, xm[4] = {0, 0, 0, 0}, xi[4] = {0, 0, 0, 0};
     if (n_ok) {
-        if (p.bias) load4(p.bias + n_base, bias);
-        if (p.epi != PSSR_EPI_STORE) { load4(p.aux_scale + n_base, xs); load4(p.aux_shift + n_base, xh); }
+        if (p.bias) {
+            if (p.epi == PSSR_EPI_FINAL) { for (int e = 0; e < 4; ++e) if (n_base + e < p.cout) bias[e] = p.bias[n_base + e]; }
+            else load4(p.bias + n_base, bias);
+        }
+        if (p.epi == PSSR_EPI_TAIL || p.epi == PSSR_EPI_DGRAD_MASK) { load4(p.aux_scale + n_base, xs); load4(p.aux_shift + n_base, xh); }
         if (p.epi == PSSR_EPI_DGRAD_MASK && (p.flags & PSSR_FLAG_STATS)) {
             load4(p.aux_mean + n_base, xm); load4(p.aux_invstd + n_base, xi);
         }
@@ -240,9 +253,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
             const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
             if (!(n_ok && gi < p.N && gy < p.H && gx < p.W)) continue;
-            const long pix = ((long)gi * p.H + gy) * p.W + gx;
             float v[4];
             load4(Es + row * BN + c4 * 4, v);
+            if (p.epi == PSSR_EPI_FINAL) {
+                float* of = (float*)p.out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n_base + e < p.cout)
+                        of[(((long)gi * p.cout + n_base + e) * p.H + gy) * p.W + gx] = fmaf(v[e] + bias[e], p.out_scale, p.out_shift);
+                continue;
+            }
+            const long pix = pix_index(gi, gy, gx, p.H, p.W, p.out_blk);
             if (p.epi == PSSR_EPI_STORE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 }
             } else {
                 float a[4];
-                load4(auxp + pix * p.aux_cs + p.aux_co + n_base, a);
+                load4(auxp + pix_index(gi, gy, gx, p.H, p.W, p.aux_blk) * p.aux_cs + p.aux_co + n_base, a);
                 if (p.epi == PSSR_EPI_TAIL) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
@@ -308,7 +329,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
@@ -350,12 +371,21 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
         PSSR_CHECK(d->in1 && d->w1 && d->cin1 % 16 == 0 && (d->taps1 == 1 || d->taps1 == 9), PSSR_ERR_ARG, "conv2d: bad source 1");
         PSSR_CHECK((d->in1_cstride * esz) % 16 == 0 && (d->in1_coff * esz) % 16 == 0 && d->in1_coff + d->cin1 <= d->in1_cstride, PSSR_ERR_ARG, "conv2d: in1 stride/offset");
     }
-    PSSR_CHECK(d->cout > 0 && d->cout % 4 == 0, PSSR_ERR_ARG, "conv2d: cout=%d must be a positive multiple of 4", d->cout);
+    if (d->epilogue == PSSR_EPI_FINAL) {
+        PSSR_CHECK(d->cout > 0 && d->cout <= 32 && d->flags == 0, PSSR_ERR_ARG, "conv2d: EPI_FINAL needs 0 < cout <= 32 and no flags");
+    } else {
+        PSSR_CHECK(d->cout > 0 && d->cout % 4 == 0, PSSR_ERR_ARG, "conv2d: cout=%d must be a positive multiple of 4", d->cout);
+        PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 && d->out_coff + d->cout <= d->out_cstride, PSSR_ERR_ARG, "conv2d: out stride/offset");
+    }
     PSSR_CHECK(d->n_pad % 128 == 0 && d->n_pad >= d->cout, PSSR_ERR_ARG, "conv2d: n_pad=%d", d->n_pad);
-    PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 && d->out_coff + d->cout <= d->out_cstride, PSSR_ERR_ARG, "conv2d: out stride/offset");
     PSSR_CHECK(d->prologue == PSSR_PRO_NONE || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "conv2d: prologue needs scale/shift");
-    PSSR_CHECK(d->epilogue >= 0 && d->epilogue <= 2, PSSR_ERR_ARG, "conv2d: epilogue=%d", d->epilogue);
-    if (d->epilogue != PSSR_EPI_STORE) {
+    PSSR_CHECK(d->epilogue >= 0 && d->epilogue <= 3, PSSR_ERR_ARG, "conv2d: epilogue=%d", d->epilogue);
+    PSSR_CHECK(d->in0_blk >= 0 && d->out_blk >= 0 && d->aux_blk >= 0 && d->in0_blk <= 3 && d->out_blk <= 3 && d->aux_blk <= 3, PSSR_ERR_ARG, "conv2d: blocked order");
+    {
+        const int mb = d->in0_blk > d->out_blk ? (d->in0_blk > d->aux_blk ? d->in0_blk : d->aux_blk) : (d->out_blk > d->aux_blk ? d->out_blk : d->aux_blk);
+        PSSR_CHECK(d->h % (1 << mb) == 0 && d->w % (1 << mb) == 0, PSSR_ERR_ARG, "conv2d: blocked order needs H,W multiples of r");
+    }
+    if (d->epilogue == PSSR_EPI_TAIL || d->epilogue == PSSR_EPI_DGRAD_MASK) {
         PSSR_CHECK(d->aux && d->aux_scale && d->aux_shift && d->aux_coff % 4 == 0 && d->aux_cstride % 4 == 0, PSSR_ERR_ARG, "conv2d: epilogue needs aux tensor");
     }
     if (d->flags & PSSR_FLAG_STATS) {
@@ -373,6 +403,8 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     a.aux = d->aux; a.aux_cs = d->aux_cstride; a.aux_co = d->aux_coff;
     a.aux_scale = d->aux_scale; a.aux_shift = d->aux_shift; a.aux_mean = d->aux_mean; a.aux_invstd = d->aux_invstd;
     a.stats = d->stats;
+    a.in0_blk = d->in0_blk; a.out_blk = d->out_blk; a.aux_blk = d->aux_blk;
+    a.out_scale = d->out_scale; a.out_shift = d->out_shift;
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : launch_bn<float>(a, s);

@@ -1,0 +1,271 @@
+// Weight gradient of the 3x3 / 1x1 convolution for gfx950:  dW[n][tap][k] = sum_pixels dy[p][n] * a[p+tap][k]
+//
+// GEMM view per tap: rows = output channels n, columns = input channels k, reduction = pixels.  Both
+// operands are pixel-major (NHWC) in memory, i.e. the reduction index is the *strided* one, so the
+// MFMA fragments (8 consecutive reduction elements per lane) are fetched from LDS with the CDNA4
+// transposing read ds_read_b64_tr_b16 (bf16 build) or with plain 4-byte reads feeding
+// v_mfma_f32_32x32x2_f32 (exact-f32 build).  A workgroup owns a (CO_T x CI_T x taps) slab of dW,
+// keeps all of it in accumulators (9 tiles per wave), and walks a strided subset of the pixel
+// tiles; per tile it stages dy (128 px) and the input halo tile once and reuses the halo for the 9
+// taps.  Partial slabs are combined with f32 atomics (one add per element per workgroup).
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+    int N, H, W;
+    int tiles_x, tiles_y, tiles_i, n_tiles, split;
+    const void* dy; int dy_cs, dy_co, dy_blk, cout;        // rows of dW
+    const void* in; int in_cs, in_co, in_blk, cin_pad;     // columns of dW (k), multiple of 16
+    int taps;
+    int prologue; const float* pro_scale; const float* pro_shift;
+    float* dw;                                             // [cout][taps][cin_pad] f32, atomically accumulated
+    int co_tiles, ci_tiles;
+};
+
+template <int GEO> struct WGeo;
+template <> struct WGeo<0> { static constexpr int TWL = 4, THL = 3; };
+template <> struct WGeo<1> { static constexpr int TWL = 3, THL = 3; };
+template <> struct WGeo<2> { static constexpr int TWL = 2, THL = 2; };
+
+// fragment fetch: 8 (bf16) / 4 (f32) reduction rows for one 32-wide channel sub-tile
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+    static constexpr int KP = 16;   // pixels per k-step
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    // `rowaddr0/1`: LDS byte address of (this lane's row q, its 4 columns) for reduction rows q and q+4
+    static __device__ __forceinline__ uint4 load(const char* a0, const char* a1) {
+        union { s16x4 v[2]; uint4 u; } r;
+        r.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        r.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        return r.u;
+    }
+};
+
+template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+    using X = TT<T>;
+    constexpr int EPS = X::EPS;
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI;
+    constexpr int ROWB = 32 * (int)sizeof(T);            // bytes per LDS row (32 channels)
+    constexpr int PPS = ROWB / 16;                        // 16-byte pieces per sub-tile row
+    constexpr int CO_S = CO_T / 32, CI_S = CI_T / 32;     // 32-channel sub-tiles
+    static_assert(CO_S * CI_S == 4, "one (cout sub, cin sub) pair per wave");
+    constexpr int DY_BYTES = CO_S * 128 * ROWB, AH_BYTES = CI_S * HP * ROWB;
+    constexpr int DY_PIECES = 128 * CO_S * PPS, AH_PIECES = HP * CI_S * PPS;
+    constexpr int KP = (sizeof(T) == 2) ? 16 : 8;         // pixels per k-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Dy = smem;
+    char* Ah = smem + DY_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cosub = wave % CO_S, cisub = wave / CO_S;
+    const int ct = blockIdx.y;
+    const int n0 = (ct % p.co_tiles) * CO_T, k0 = (ct / p.co_tiles) * CI_T;
+    const T* dyp = (const T*)p.dy;
+    const T* inp = (const T*)p.in;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const char* dy_img = Dy + cosub * 128 * ROWB;
+    const char* ah_img = Ah + cisub * HP * ROWB;
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += p.split) {
+        int tmi = tile;
+        const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
+        const int tile_y = tmi % p.tiles_y;
+        const int tile_i = tmi / p.tiles_y;
+        const int x0 = tile_x << TWL, y0 = tile_y << THL, img0 = tile_i * NI;
+
+        // ---- stage dy tile: [cout sub][pixel m][32 ch]
+        for (int idx = tid; idx < DY_PIECES; idx += 256) {
+            const int m = idx / (CO_S * PPS), pc = idx % (CO_S * PPS);
+            const int sub = pc / PPS, pin = pc % PPS;
+            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
+            const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
+            const int ch = n0 + pc * EPS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gi < p.N && gy < p.H && gx < p.W && ch < p.cout)
+                v = *(const uint4*)(dyp + pix_index(gi, gy, gx, p.H, p.W, p.dy_blk) * p.dy_cs + p.dy_co + ch);
+            *(uint4*)(Dy + sub * 128 * ROWB + m * ROWB + pin * 16) = v;
+        }
+        // ---- stage input halo tile: [cin sub][halo pixel][32 ch], BN+ReLU applied in flight
+        for (int idx = tid; idx < AH_PIECES; idx += 256) {
+            const int pp = idx / (CI_S * PPS), pc = idx % (CI_S * PPS);
+            const int sub = pc / PPS, pin = pc % PPS;
+            const int img = pp / HPI, rem = pp % HPI;
+            const int hy = rem / HW2, hx = rem % HW2;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
+            const int ch = k0 + pc * EPS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ch < p.cin_pad) {
+                v = *(const uint4*)(inp + pix_index(gi, gy, gx, p.H, p.W, p.in_blk) * p.in_cs + p.in_co + ch);
+                if (p.prologue == PSSR_PRO_BN_RELU) {
+                    float f[EPS];
+                    X::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < EPS; e += 4) {
+                        const float4 sc = *(const float4*)(p.pro_scale + ch + e);
+                        const float4 sh = *(const float4*)(p.pro_shift + ch + e);
+                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);
+                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);
+                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);
+                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);
+                    }
+                    v = X::pack(f);
+                }
+            }
+            *(uint4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;
+        }
+        __syncthreads();
+
+        // ---- multiply: 128/KP k-steps x taps
+
+        for (int s = 0; s < 128 / KP; ++s) {
+            uint4 af;
+            int hb[2];   // halo byte offsets of this lane's reduction rows (tap (0,0))
+            if constexpr (sizeof(T) == 2) {
+                // ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
+                const int g = lane >> 4, i = lane & 15, q = i >> 2, pcol = i & 3;
+                const int colb = ((g & 1) * 16 + pcol * 4) * 2;
+                const int m0 = s * 16 + (g >> 1) * 8 + q;
+                af = Frag<bf16_t>::load(dy_img + m0 * ROWB + colb, dy_img + (m0 + 4) * ROWB + colb);
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int m = m0 + 4 * rd;
+                    const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
+                    hb[rd] = (img * HPI + ty * HW2 + tx) * ROWB + colb;
+                }
+            } else {
+                // 4 x 32x32x2: MFMA t consumes reduction rows s*8 + 4h + t; lane r reads channel r of that row
+                const int r = lane & 31, h = lane >> 5;
+                const int m0 = s * 8 + 4 * h;
+                float a4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = *(const float*)(dy_img + (m0 + t) * ROWB + r * 4);
+                af = make_uint4(__float_as_uint(a4[0]), __float_as_uint(a4[1]), __float_as_uint(a4[2]), __float_as_uint(a4[3]));
+                const int tx = m0 & (TW - 1), ty = (m0 >> TWL) & (TH - 1), img = m0 >> (TWL + THL);
+                hb[0] = (img * HPI + ty * HW2 + tx) * ROWB + r * 4;   // rows m0..m0+3 are consecutive in x when TW >= 4
+                hb[1] = 0;
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int ky = (TAPS == 9) ? t / 3 : 1, kx = (TAPS == 9) ? t % 3 : 1;
+                const int toff = (ky * HW2 + kx) * ROWB;
+                uint4 bf;
+                if constexpr (sizeof(T) == 2) {
+                    bf = Frag<bf16_t>::load(ah_img + hb[0] + toff, ah_img + hb[1] + toff);
+                } else {
+                    float b4[4];
+                    if constexpr (TW >= 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) b4[u] = *(const float*)(ah_img + hb[0] + toff + u * ROWB);
+                    } else {
+                        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int m = s * 8 + 4 * h + u;
+                            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
+                            b4[u] = *(const float*)(ah_img + (img * HPI + ty * HW2 + tx) * ROWB + r * 4 + toff);
+                        }
+                    }
+                    bf = make_uint4(__float_as_uint(b4[0]), __float_as_uint(b4[1]), __float_as_uint(b4[2]), __float_as_uint(b4[3]));
+                }
+                X::mma(acc[t], af, bf);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- combine: dW[n][tap][k] += acc
+    const int kcol = k0 + cisub * 32 + (lane & 31);
+    if (kcol < p.cin_pad) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + cosub * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (n < p.cout) atomicAdd(p.dw + ((long)n * TAPS + t) * p.cin_pad + kcol, acc[t][e]);
+            }
+        }
+    }
+}
+
+template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
+int launch_t(WgradArgs p, hipStream_t stream) {
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    constexpr int HP = NI * (TH + 2) * (TW + 2);
+    constexpr int ROWB = 32 * (int)sizeof(T);
+    constexpr int LDS = (CO_T / 32) * 128 * ROWB + (CI_T / 32) * HP * ROWB;
+    p.tiles_x = cdiv(p.W, TW); p.tiles_y = cdiv(p.H, TH); p.tiles_i = cdiv(p.N, NI);
+    p.n_tiles = p.tiles_x * p.tiles_y * p.tiles_i;
+    p.co_tiles = cdiv(p.cout, CO_T); p.ci_tiles = cdiv(p.cin_pad, CI_T);
+    const int slabs = p.co_tiles * p.ci_tiles;
+    int split = cdiv(1024, slabs);
+    if (split > p.n_tiles) split = p.n_tiles;
+    if (split < 1) split = 1;
+    p.split = split;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, CO_T, CI_T, GEO, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, CO_T, CI_T, GEO, TAPS>), dim3(split, slabs), dim3(256), LDS, stream, p);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+template <typename T, int CO_T, int CI_T, int GEO>
+int launch(const WgradArgs& p, hipStream_t stream) {
+    return p.taps == 9 ? launch_t<T, CO_T, CI_T, GEO, 9>(p, stream) : launch_t<T, CO_T, CI_T, GEO, 1>(p, stream);
+}
+
+template <typename T, int CO_T, int CI_T>
+int launch_geo(const WgradArgs& a, hipStream_t s) {
+    const int w = a.W;
+    if (w > 8) return launch<T, CO_T, CI_T, 0>(a, s);
+    if (w > 4) return launch<T, CO_T, CI_T, 1>(a, s);
+    if (w > 2) return launch<T, CO_T, CI_T, 2>(a, s);
+    // 2x2 / 1x1 images: the 9x halo blow-up does not fit LDS; training at such sizes is out of scope
+    pssr_set_error("wgrad: spatial width %d < 3 is not supported", w);
+    return PSSR_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_shape(const WgradArgs& a, hipStream_t s) {
+    if (a.cout > 64 && a.cin_pad <= 32) return launch_geo<T, 128, 32>(a, s);
+    if (a.cout <= 32) return launch_geo<T, 32, 128>(a, s);
+    return launch_geo<T, 64, 64>(a, s);
+}
+
+}  // namespace
+
+extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream) {
+    PSSR_CHECK(d != nullptr, PSSR_ERR_ARG, "wgrad: null desc");
+    PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16, PSSR_ERR_ARG, "wgrad: bad dtype %d", d->dtype);
+    const int esz = d->dtype == PSSR_BF16 ? 2 : 4;
+    PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "wgrad: bad shape");
+    PSSR_CHECK(d->dy && d->in && d->dw, PSSR_ERR_ARG, "wgrad: null pointer");
+    PSSR_CHECK(d->taps == 9 || d->taps == 1, PSSR_ERR_ARG, "wgrad: taps=%d", d->taps);
+    PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % 16 == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of 16", d->cin_pad);
+    PSSR_CHECK(d->cout > 0 && (d->cout * esz) % 16 == 0, PSSR_ERR_ARG, "wgrad: cout=%d must fill whole 16-byte slots", d->cout);
+    PSSR_CHECK((d->dy_cstride * esz) % 16 == 0 && (d->dy_coff * esz) % 16 == 0 && d->dy_coff + d->cout <= d->dy_cstride, PSSR_ERR_ARG, "wgrad: dy stride/offset");
+    PSSR_CHECK((d->in_cstride * esz) % 16 == 0 && (d->in_coff * esz) % 16 == 0 && d->in_coff + d->cin_pad <= d->in_cstride, PSSR_ERR_ARG, "wgrad: in stride/offset");
+    PSSR_CHECK(d->prologue == PSSR_PRO_NONE || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "wgrad: prologue needs scale/shift");
+    PSSR_CHECK(d->dy_blk >= 0 && d->in_blk >= 0 && (d->h % (1 << d->dy_blk)) == 0 && (d->w % (1 << d->in_blk)) == 0, PSSR_ERR_ARG, "wgrad: blocked layout");
+    WgradArgs a;
+    a.N = d->n; a.H = d->h; a.W = d->w;
+    a.dy = d->dy; a.dy_cs = d->dy_cstride; a.dy_co = d->dy_coff; a.dy_blk = d->dy_blk; a.cout = d->cout;
+    a.in = d->in; a.in_cs = d->in_cstride; a.in_co = d->in_coff; a.in_blk = d->in_blk; a.cin_pad = d->cin_pad;
+    a.taps = d->taps; a.prologue = d->prologue; a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
+    a.dw = d->dw;
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s) : launch_shape<float>(a, s);
+}

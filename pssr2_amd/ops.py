@@ -55,7 +55,8 @@ def pack_conv_weight(w: torch.Tensor, dtype: int, mode: int = 0, ci_begin: int =
 def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_coff=0, bias=None,
            x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
            pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
-           aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None):
+           aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None,
+           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0):
     """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff)."""
     d = L.ConvDesc()
     d.dtype = w0.dtype
@@ -73,5 +74,31 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
         d.aux, d.aux_cstride, d.aux_coff = L.ptr(aux), aux.shape[-1], aux_coff
     d.aux_scale, d.aux_shift, d.aux_mean, d.aux_invstd = L.ptr(aux_scale), L.ptr(aux_shift), L.ptr(aux_mean), L.ptr(aux_invstd)
     d.stats = L.ptr(stats)
+    d.in0_blk, d.out_blk, d.aux_blk, d.out_scale, d.out_shift = in0_blk, out_blk, aux_blk, out_scale, out_shift
+    if epilogue == L.EPI_FINAL:      # f32 NCHW output [n, cout, h, w]
+        d.out_cstride, d.out_coff = cout, 0
     L.check(L.lib().pssr_conv2d(C.byref(d), L.stream_ptr()), "pssr_conv2d")
     return out
+
+
+def conv2d_wgrad(dy, cout, x, cin_pad, taps, dw, *, n, h, w, dtype, dy_coff=0, in_coff=0, dy_blk=0, in_blk=0,
+                 pro_scale=None, pro_shift=None):
+    """dw (f32 [cout, taps, cin_pad], zeroed by the caller) += dy^T (*) prologue(x)."""
+    d = L.WgradDesc()
+    d.dtype, d.n, d.h, d.w = dtype, n, h, w
+    d.dy, d.dy_cstride, d.dy_coff, d.dy_blk, d.cout = L.ptr(dy), dy.shape[-1], dy_coff, dy_blk, cout
+    d.in_, d.in_cstride, d.in_coff, d.in_blk, d.cin_pad = L.ptr(x), x.shape[-1], in_coff, in_blk, cin_pad
+    d.taps = taps
+    d.prologue = L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
+    d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
+    d.dw = L.ptr(dw)
+    L.check(L.lib().pssr_conv2d_wgrad(C.byref(d), L.stream_ptr()), "pssr_conv2d_wgrad")
+    return dw
+
+
+def unpack_conv_wgrad(dw_packed, dw_oihw, *, mode=0, ci_begin=0, ci_count=None, n_perm=None, k_pad, accumulate=False):
+    cout, cin, ks, _ = dw_oihw.shape
+    ci_count = cin - ci_begin if ci_count is None else ci_count
+    L.check(L.lib().pssr_unpack_conv_wgrad(L.ptr(dw_packed), L.ptr(dw_oihw), cout, cin, ks, ci_begin, ci_count, mode,
+                                           L.ptr(n_perm), k_pad, int(accumulate), L.stream_ptr()), "pssr_unpack_conv_wgrad")
+    return dw_oihw

@@ -155,3 +155,42 @@ def test_conv_two_sources_and_errors():
     np.testing.assert_allclose(out.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
     with pytest.raises(RuntimeError, match="cin0"):
         ops.conv2d(_nhwc(x0, c0, torch.float32), 24 + 1, pw0, out, cout, n=n, h=h, w=w)
+
+
+WG_CASES = [
+    # n, cin, cout, h, w, ks
+    (2, 16, 64, 16, 16, 3),
+    (1, 32, 128, 24, 40, 3),
+    (3, 48, 16, 8, 8, 3),
+    (9, 64, 32, 4, 4, 3),
+    (2, 64, 256, 16, 16, 1),
+    (2, 80, 24, 12, 20, 3),
+    (4, 128, 128, 32, 32, 3),
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(case, dt):
+    from pssr2_amd import ops
+    n, cin, cout, h, w, ks = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    code = ops.dtype_code(dt)
+    yprev = torch.randn(n, cin, h, w, generator=g)
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    dy = torch.randn(n, cout, h, w, generator=g)
+    a = F.relu(yprev.to(dt).float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(a, (cout, cin, ks, ks), dy.to(dt).float(), padding=ks // 2)
+    cpad = ops.pad_to(cin, 16)
+    copad = ops.pad_to(cout, 16)
+    sc = torch.zeros(cpad); sc[:cin] = scale
+    sh = torch.zeros(cpad); sh[:cin] = shift
+    co_eff = cout if (cout * (2 if dt == torch.bfloat16 else 4)) % 16 == 0 else copad
+    dwp = torch.zeros(co_eff, ks * ks, cpad, device="cuda")
+    ops.conv2d_wgrad(_nhwc(dy, copad, dt), co_eff, _nhwc(yprev, cpad, dt), cpad, ks * ks, dwp, n=n, h=h, w=w, dtype=code,
+                     pro_scale=sc.cuda(), pro_shift=sh.cuda())
+    dw = torch.full((cout, cin, ks, ks), 9.0, device="cuda")
+    ops.unpack_conv_wgrad(dwp, dw, k_pad=cpad)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * ref.abs().max().item())
