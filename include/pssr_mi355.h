@@ -45,6 +45,7 @@ const char* pssr_last_error(void);
  *                    GEMM-N = output channels (optionally permuted by `n_perm`: n_src = n_perm[n]).
  * mode 1 (dgrad):    GEMM-K = output channels, GEMM-N = input channels of the range, taps flipped.
  * mode 2 (flat-K):   a KxK conv seen as 1x1 over im2col'ed channels: K index = (ci-ci_begin)*ks*ks + tap.
+ * mode 3 (flat-K dgrad): the transpose of mode 2: GEMM-K = output channels, GEMM-N = flat index.
  * `k_pad` = GEMM-K rounded up to 16, `n_pad` = GEMM-N rounded up to 128 (zero filled).
  */
 int pssr_pack_conv_weight(const float* w_oihw, void* packed, int cout, int cin, int ks,
@@ -121,6 +122,79 @@ typedef struct pssr_wgrad_desc {
 } pssr_wgrad_desc;
 
 int pssr_conv2d_wgrad(const pssr_wgrad_desc* desc, pssr_stream_t stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-channel and pointwise kernels around the convolutions (all HBM-bound).
+ * NHWC tensor slices are passed as (pointer, channel stride, channel offset); C % 4 == 0.
+ */
+
+/* stats[0:c] += sum, stats[c:2c] += sum of squares of (x*pre_scale + pre_shift) over N,H,W of an
+ * NCHW f32 tensor: batch statistics of ResUNet.norm on "x/128-1" (pssr/models/resunet.py:66-68). */
+int pssr_channel_stats_nchw(const float* x, int n, int c, int64_t hw, float pre_scale, float pre_shift,
+                            double* stats, pssr_stream_t stream);
+
+/* nn.BatchNorm2d training-mode bookkeeping (pssr/models/_blocks.py:31; torch defaults eps=1e-5,
+ * momentum=.1): from [sum, sumsq] -> scale=gamma*invstd, shift=beta-mean*scale, mean, invstd and the
+ * running_mean / running_var update (unbiased variance).  running_* may both be NULL. */
+int pssr_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                     float* mean, float* invstd, int c, pssr_stream_t stream);
+/* eval mode: scale/shift from the running statistics */
+int pssr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift, int c,
+                        pssr_stream_t stream);
+/* BatchNorm backward: with stats = [sum g, sum g*xhat] the input gradient is A*g + B*y + C per channel;
+ * also emits dgamma = sum g*xhat and dbeta = sum g (either may be NULL). */
+int pssr_bn_bwd_coefs(const double* stats, double count, const float* gamma, const float* mean,
+                      const float* invstd, float* coef_a, float* coef_b, float* coef_c, float* dgamma,
+                      float* dbeta, int c, pssr_stream_t stream);
+int pssr_bn_bwd_apply(const void* g, int g_cs, int g_co, const void* y, int y_cs, int y_co,
+                      const float* coef_a, const float* coef_b, const float* coef_c,
+                      void* dy, int dy_cs, int dy_co, int64_t npix, int c, int dtype, pssr_stream_t stream);
+
+/* Input stage of ResUNet.forward (resunet.py:66-70) fused with the im2col of the 3x3 neighbourhood:
+ * xcol[n,y,x, ch*9+tap] = ((x[n,ch,y+ky-1,x+kx-1]*pre_scale+pre_shift)*scale[ch]+shift[ch]), zero
+ * outside the image, channels [9c, xc) zero.  The first conv, the first respass and the input
+ * channel of Reconstruction.pre then run as flat-K 1x1 convolutions over xcol. */
+int pssr_input_im2col(const float* x_nchw, void* xcol, int n, int c, int h, int w, int xc,
+                      float pre_scale, float pre_shift, const float* scale, const float* shift,
+                      int dtype, pssr_stream_t stream);
+/* backward of the above for the parameters of ResUNet.norm: folds d(xcol) (two optional sources)
+ * onto the normalised input and accumulates stats = [sum dx0, sum dx0*xhat0] per input channel. */
+int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const float* x_nchw,
+                        float pre_scale, float pre_shift, const float* mean, const float* invstd,
+                        int n, int c, int h, int w, double* stats, int dtype, pssr_stream_t stream);
+
+/* F.max_pool2d(x, 2) (resunet.py:76) and its gradient; the gradient goes to the first maximum of
+ * each window and is added to `dskip` (the skip-connection gradient of the same tensor, may be NULL). */
+int pssr_maxpool2(const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
+                  int n, int h, int w, int c, int dtype, pssr_stream_t stream);
+int pssr_maxpool2_bwd(const void* act, int act_cs, int act_co, const void* dpool, int dp_cs, int dp_co,
+                      const void* dskip, int ds_cs, int ds_co, void* dout, int do_cs, int do_co,
+                      int n, int h, int w, int c, int dtype, pssr_stream_t stream);
+
+/* F.pixel_shuffle(x, r) (resunet.py:82) written straight into a channel slice of the concat buffer
+ * (torch.cat at resunet.py:84 is never materialised separately); inverse=1 is the gradient. */
+int pssr_pixel_shuffle(const void* lo, int lo_cs, int lo_co, void* hi, int hi_cs, int hi_co,
+                       int n, int h, int w, int c_hi, int r, int inverse, int dtype, pssr_stream_t stream);
+
+/* backward of "relu(bn(y) + r)" (ResBlock tail, _blocks.py:40): dz = dout*(out>0) and
+ * stats += [sum dz, sum dz*xhat(y)] for the BatchNorm in front of the addition. */
+int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out, int o_cs, int o_co,
+                        const void* y, int y_cs, int y_co, const float* mean, const float* invstd,
+                        void* dz, int dz_cs, int dz_co, double* stats, int64_t npix, int c, int dtype,
+                        pssr_stream_t stream);
+
+/* out[c] += sum over pixels (bias gradients) */
+int pssr_channel_sum_nhwc(const void* x, int cs, int co, int64_t npix, int c, double* out, int dtype,
+                          pssr_stream_t stream);
+/* f32 NCHW -> NHWC in the compute dtype, scaled, channels [c, out_cs) zero (gradient of the output) */
+int pssr_nchw_to_nhwc(const float* in, void* out, int n, int c, int64_t hw, int out_cs, float scale,
+                      int dtype, pssr_stream_t stream);
+/* np.clip(x, 0, 255).astype(np.uint8): truncation toward zero (pssr/predict.py:245-246) */
+int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t stream);
+int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, pssr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,27 +32,35 @@ def _bn(x, sd, prefix, train, new_stats):
     return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
 
 
-def resblock_forward(x, sd, prefix, depth, train, new_stats):
+def _rec(record, name, t):
+    if record is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        record[name] = t
+    return t
+
+
+def resblock_forward(x, sd, prefix, depth, train, new_stats, record=None):
     """pssr/models/_blocks.py:39-41 with the Sequential laid out as at :26-33."""
     n_layers = max(depth, 0) + 1
     h = x
     for i in range(n_layers):
-        h = F.conv2d(h, sd[f"{prefix}.conv.{3 * i}.weight"], sd[f"{prefix}.conv.{3 * i}.bias"], padding=1)
+        h = _rec(record, f"{prefix}.y{i}", F.conv2d(h, sd[f"{prefix}.conv.{3 * i}.weight"], sd[f"{prefix}.conv.{3 * i}.bias"], padding=1))
         h = _bn(h, sd, f"{prefix}.conv.{3 * i + 1}", train, new_stats)
         if i + 1 < n_layers:
             h = F.relu(h)
     r = F.conv2d(x, sd[f"{prefix}.respass.weight"], sd[f"{prefix}.respass.bias"])
-    return F.relu(h + r)
+    return _rec(record, f"{prefix}.out", F.relu(h + r))
 
 
-def reconstruction_forward(x, sd, prefix, scale):
+def reconstruction_forward(x, sd, prefix, scale, record=None):
     """pssr/models/_blocks.py:15-18."""
-    x = F.relu(F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1))
+    x = _rec(record, f"{prefix}.pre_out", F.relu(F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1)))
     x = F.pixel_shuffle(x, scale)
     return F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], padding=1)
 
 
-def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False):
+def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None):
     """ResUNet.forward (pssr/models/resunet.py:65-96), non-atrous, no PSP pooling.
 
     ``x``: float32 [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats).
@@ -62,17 +70,18 @@ def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False):
     x = _bn(x, sd, "norm", train, new_stats)
     skips = [x]
     for i in range(n_levels):
-        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats)
+        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats, record)
         if i + 1 < n_levels:
             skips.append(x)
             x = F.max_pool2d(x, kernel_size=2)
     for j in range(n_levels - 1):
         x = F.pixel_shuffle(x, 2)
         x = torch.cat([x, skips.pop()], dim=1)
-        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats)
+        x = _rec(record, f"decoder.{j}.in", x)
+        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats, record)
     x = torch.cat([x, skips.pop()], dim=1)
     assert not skips
-    x = reconstruction_forward(x, sd, "reconstruction", scale)
+    x = reconstruction_forward(x, sd, "reconstruction", scale, record)
     return x * 128 + 128, new_stats
 
 

@@ -363,12 +363,12 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     const int esz = d->dtype == PSSR_BF16 ? 2 : 4;
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "conv2d: bad shape %dx%dx%d", d->n, d->h, d->w);
     PSSR_CHECK(d->in0 && d->w0 && d->out, PSSR_ERR_ARG, "conv2d: null pointer");
-    PSSR_CHECK(d->cin0 > 0 && d->cin0 % 16 == 0, PSSR_ERR_ARG, "conv2d: cin0=%d must be a positive multiple of 16", d->cin0);
+    PSSR_CHECK(d->cin0 > 0 && d->cin0 % kch == 0, PSSR_ERR_ARG, "conv2d: cin0=%d must be a positive multiple of %d", d->cin0, kch);
     PSSR_CHECK(d->taps0 == 9 || d->taps0 == 1, PSSR_ERR_ARG, "conv2d: taps0=%d", d->taps0);
     PSSR_CHECK((d->in0_cstride * esz) % 16 == 0 && (d->in0_coff * esz) % 16 == 0, PSSR_ERR_ARG, "conv2d: in0 stride/offset not 16-byte aligned");
     PSSR_CHECK(d->in0_coff + d->cin0 <= d->in0_cstride, PSSR_ERR_ARG, "conv2d: in0 slice exceeds stride");
     if (d->cin1) {
-        PSSR_CHECK(d->in1 && d->w1 && d->cin1 % 16 == 0 && (d->taps1 == 1 || d->taps1 == 9), PSSR_ERR_ARG, "conv2d: bad source 1");
+        PSSR_CHECK(d->in1 && d->w1 && d->cin1 % kch == 0 && (d->taps1 == 1 || d->taps1 == 9), PSSR_ERR_ARG, "conv2d: bad source 1");
         PSSR_CHECK((d->in1_cstride * esz) % 16 == 0 && (d->in1_coff * esz) % 16 == 0 && d->in1_coff + d->cin1 <= d->in1_cstride, PSSR_ERR_ARG, "conv2d: in1 stride/offset");
     }
     if (d->epilogue == PSSR_EPI_FINAL) {

@@ -254,7 +254,7 @@ extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream)
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "wgrad: bad shape");
     PSSR_CHECK(d->dy && d->in && d->dw, PSSR_ERR_ARG, "wgrad: null pointer");
     PSSR_CHECK(d->taps == 9 || d->taps == 1, PSSR_ERR_ARG, "wgrad: taps=%d", d->taps);
-    PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % 16 == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of 16", d->cin_pad);
+    PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % (d->dtype == PSSR_BF16 ? 16 : 8) == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of the K-chunk", d->cin_pad);
     PSSR_CHECK(d->cout > 0 && (d->cout * esz) % 16 == 0, PSSR_ERR_ARG, "wgrad: cout=%d must fill whole 16-byte slots", d->cout);
     PSSR_CHECK((d->dy_cstride * esz) % 16 == 0 && (d->dy_coff * esz) % 16 == 0 && d->dy_coff + d->cout <= d->dy_cstride, PSSR_ERR_ARG, "wgrad: dy stride/offset");
     PSSR_CHECK((d->in_cstride * esz) % 16 == 0 && (d->in_coff * esz) % 16 == 0 && d->in_coff + d->cin_pad <= d->in_cstride, PSSR_ERR_ARG, "wgrad: in stride/offset");

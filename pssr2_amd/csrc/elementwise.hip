@@ -1,0 +1,528 @@
+// HBM-bound pointwise / per-channel kernels around the convolutions: input normalisation + im2col,
+// BatchNorm finalisation and backward, max-pool, pixel (un)shuffle, ReLU backward, layout changes.
+// All NHWC kernels move 4 channels (8 or 16 bytes) per thread with consecutive lanes on consecutive
+// channels, so every wave touches whole 128-byte lines; per-channel reductions are accumulated in
+// registers (a thread keeps one channel group for its whole life), combined across the workgroup in
+// LDS and added to the f64 result with one atomic per channel per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct Ref { const void* p; int cs, co; };   // NHWC tensor slice: base, channel stride, channel offset
+struct MRef { void* p; int cs, co; };
+
+template <typename T> __device__ __forceinline__ const T* at(const Ref& r, long pix, int c) { return (const T*)r.p + pix * r.cs + r.co + c; }
+template <typename T> __device__ __forceinline__ T* at(const MRef& r, long pix, int c) { return (T*)r.p + pix * r.cs + r.co + c; }
+
+// Thread -> (pixel lane, channel group) assignment shared by every per-channel kernel.
+struct ChanMap {
+    int cg_count, threads, ppb;   // channel groups, active threads per block, pixels per block-iteration
+    __device__ __forceinline__ bool active() const { return (int)threadIdx.x < threads; }
+};
+static ChanMap make_map(int c) {
+    ChanMap m;
+    m.cg_count = c / 4;
+    if (m.cg_count <= TPB) { m.ppb = TPB / m.cg_count; m.threads = m.ppb * m.cg_count; }
+    else { m.ppb = 1; m.threads = TPB; }
+    return m;
+}
+static int grid_for(long npix, const ChanMap& m) {
+    long b = (npix + m.ppb - 1) / m.ppb;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+// Block-level combine of NS per-thread sums of 4 channels each, then f64 atomics: dst[s*C + c]
+template <int NS>
+__device__ __forceinline__ void flush_sums(const ChanMap& m, int cg, float (*acc)[4], double* dst, int C, float* lds) {
+    // lds: [TPB][NS*4]
+    if (m.cg_count <= TPB) {
+        const int tid = threadIdx.x;
+        if (m.active())
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lds[tid * NS * 4 + s * 4 + e] = acc[s][e];
+        __syncthreads();
+        if (tid < m.cg_count) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = 0.f;
+                    for (int pl = 0; pl < m.ppb; ++pl) t += lds[(pl * m.cg_count + tid) * NS * 4 + s * 4 + e];
+                    atomicAdd(dst + (long)s * C + tid * 4 + e, (double)t);
+                }
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dst + (long)s * C + cg * 4 + e, (double)acc[s][e]);
+    }
+}
+
+// Iterates this thread's (pixel, channel-group) items: F(pix, c0) ; calls G(cg) after each group is done.
+template <class F, class G>
+__device__ __forceinline__ void for_items(const ChanMap& m, long npix, F f, G done) {
+    if (m.cg_count <= TPB) {
+        const int cg = threadIdx.x % m.cg_count, pl = threadIdx.x / m.cg_count;
+        if (m.active())
+            for (long pix = (long)blockIdx.x * m.ppb + pl; pix < npix; pix += (long)gridDim.x * m.ppb) f(pix, cg * 4);
+        done(cg);
+    } else {
+        for (int cg = threadIdx.x; cg < m.cg_count; cg += TPB) {
+            for (long pix = blockIdx.x; pix < npix; pix += gridDim.x) f(pix, cg * 4);
+            done(cg);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_stats_kernel(const float* __restrict__ x, int n, int c, long hw, float ps, float pb, double* stats) {
+    // one (image, channel) plane chunk per block column; grid = (chunks, n*c)
+    const int plane = blockIdx.y, ch = plane % c;
+    const float* src = x + (long)plane * hw;
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < hw; i += (long)gridDim.x * TPB) {
+        const float v = fmaf(src[i], ps, pb);
+        s1 += v; s2 += v * v;
+    }
+    __shared__ float r1[TPB], r2[TPB];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(stats + ch, (double)r1[0]); atomicAdd(stats + c + ch, (double)r2[0]); }
+}
+
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                   float* rmean, float* rvar, float* scale, float* shift, float* mean, float* invstd, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const double mu = stats[i] / count;
+    double var = stats[c + i] / count - mu * mu;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
+    scale[i] = g * is;
+    shift[i] = b - (float)mu * g * is;
+    if (mean) mean[i] = (float)mu;
+    if (invstd) invstd[i] = is;
+    if (rmean) {
+        const double unbiased = count > 1 ? var * count / (count - 1) : var;
+        rmean[i] = (1.f - momentum) * rmean[i] + momentum * (float)mu;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                               float* scale, float* shift, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float is = 1.f / sqrtf(rvar[i] + eps);
+    scale[i] = gamma[i] * is;
+    shift[i] = beta[i] - rmean[i] * gamma[i] * is;
+}
+
+__global__ void bn_bwd_coefs_kernel(const double* stats, double count, const float* gamma, const float* mean, const float* invstd,
+                                    float* A, float* B, float* Cc, float* dgamma, float* dbeta, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const double s1 = stats[i], s2 = stats[c + i];
+    const double c1 = s1 / count, c2 = s2 / count;
+    const double g = gamma[i], is = invstd[i], mu = mean[i];
+    A[i] = (float)(g * is);
+    B[i] = (float)(-g * is * is * c2);
+    Cc[i] = (float)(g * is * (mu * is * c2 - c1));
+    if (dgamma) dgamma[i] = (float)s2;
+    if (dbeta) dbeta[i] = (float)s1;
+}
+
+// xcol[n,y,x, ch*9+tap] = bn(x[n,ch,y+ky-1,x+kx-1]/128-1) with zero padding; channels >= 9c are zero
+template <typename T>
+__global__ void input_im2col_kernel(const float* __restrict__ x, T* __restrict__ xcol, int n, int c, int h, int w, int xc,
+                                    float ps, float pb, const float* scale, const float* shift) {
+    const long total = (long)n * h * w * xc;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % xc;
+        long pix = i / xc;
+        const int px = pix % w; pix /= w;
+        const int py = pix % h;
+        const int img = pix / h;
+        float v = 0.f;
+        if (k < 9 * c) {
+            const int ch = k / 9, tap = k % 9;
+            const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
+            if (sy >= 0 && sy < h && sx >= 0 && sx < w)
+                v = fmaf(fmaf(x[(((long)img * c + ch) * h + sy) * w + sx], ps, pb), scale[ch], shift[ch]);
+        }
+        xcol[i] = (T)v;
+    }
+}
+
+// fold the gradient of xcol back onto the normalised input and reduce the input-BN parameter grads
+template <typename T>
+__global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restrict__ db, int xc, const float* __restrict__ x,
+                                      float ps, float pb, const float* mean, const float* invstd, int n, int c, int h, int w, double* stats) {
+    const int ch = blockIdx.y;
+    const long hw = (long)h * w, total = (long)n * hw;
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int img = i / hw;
+        const int py = (i % hw) / w, px = i % w;
+        float g = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // xcol[q][ch*9+tap] = x0[q + (ky-1,kx-1)]  =>  x0[p] receives dxcol[p - (ky-1,kx-1)][tap]
+            const int qy = py - (tap / 3 - 1), qx = px - (tap % 3 - 1);
+            if (qy >= 0 && qy < h && qx >= 0 && qx < w) {
+                const long q = ((long)img * h + qy) * w + qx;
+                g += (float)da[q * xc + ch * 9 + tap];
+                if (db) g += (float)db[q * xc + ch * 9 + tap];
+            }
+        }
+        const float xh = (fmaf(x[((long)img * c + ch) * hw + i % hw], ps, pb) - mean[ch]) * invstd[ch];
+        s1 += g; s2 += g * xh;
+    }
+    __shared__ float r1[TPB], r2[TPB];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(stats + ch, (double)r1[0]); atomicAdd(stats + c + ch, (double)r2[0]); }
+}
+
+template <typename T>
+__global__ void maxpool2_kernel(Ref in, MRef out, int n, int h, int w, int c) {
+    const int cg = c / 4, ho = h / 2, wo = w / 2;
+    const long total = (long)n * ho * wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        long pix = i / cg;
+        const int ox = pix % wo; pix /= wo;
+        const int oy = pix % ho;
+        const int img = pix / ho;
+        const long p00 = ((long)img * h + 2 * oy) * w + 2 * ox;
+        float a[4], b[4], cc[4], d[4], m[4];
+        load4(at<T>(in, p00, c0), a); load4(at<T>(in, p00 + 1, c0), b);
+        load4(at<T>(in, p00 + w, c0), cc); load4(at<T>(in, p00 + w + 1, c0), d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(cc[e], d[e]));
+        store4(at<T>(out, ((long)img * ho + oy) * wo + ox, c0), m);
+    }
+}
+
+// dout = dskip (+) route(dpool): the FIRST maximum in row-major window order receives the gradient (torch semantics)
+template <typename T>
+__global__ void maxpool2_bwd_kernel(Ref act, Ref dpool, Ref dskip, MRef dout, int n, int h, int w, int c) {
+    const int cg = c / 4, ho = h / 2, wo = w / 2;
+    const long total = (long)n * ho * wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        long pix = i / cg;
+        const int ox = pix % wo; pix /= wo;
+        const int oy = pix % ho;
+        const int img = pix / ho;
+        const long p00 = ((long)img * h + 2 * oy) * w + 2 * ox;
+        const long pp[4] = {p00, p00 + 1, p00 + w, p00 + w + 1};
+        float v[4][4], g[4], o[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load4(at<T>(act, pp[k], c0), v[k]);
+        load4(at<T>(dpool, ((long)img * ho + oy) * wo + ox, c0), g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dskip.p) load4(at<T>(dskip, pp[k], c0), o[k]);
+            else { o[k][0] = o[k][1] = o[k][2] = o[k][3] = 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int best = 0; float bv = v[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k][e] > bv) { bv = v[k][e]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == best) o[k][e] += g[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store4(at<T>(dout, pp[k], c0), o[k]);
+    }
+    // odd trailing rows/cols (H or W odd) take only the skip gradient
+    if ((h & 1) || (w & 1)) {
+        const long tot2 = (long)n * h * w * cg;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < tot2; i += (long)gridDim.x * blockDim.x) {
+            const int c0 = (i % cg) * 4;
+            const long pix = i / cg;
+            const int px = pix % w, py = (pix / w) % h;
+            if (py < 2 * ho && px < 2 * wo) continue;
+            float o[4] = {0, 0, 0, 0};
+            if (dskip.p) load4(at<T>(dskip, pix, c0), o);
+            store4(at<T>(dout, pix, c0), o);
+        }
+    }
+}
+
+// forward: out[n, r*y+i, r*x+j, c] = in[n, y, x, c*r*r + i*r + j]; `inverse` swaps the roles (gradient)
+template <typename T>
+__global__ void pixel_shuffle_kernel(Ref lo, MRef hi, int n, int h, int w, int c_hi, int r, int inverse) {
+    const long total = (long)n * h * r * w * r * c_hi;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % c_hi;
+        long pix = i / c_hi;
+        const int X = pix % (w * r); pix /= (w * r);
+        const int Y = pix % (h * r);
+        const int img = pix / (h * r);
+        const long phi = ((long)img * h * r + Y) * (w * r) + X;
+        const long plo = ((long)img * h + Y / r) * w + X / r;
+        const int clo = c * r * r + (Y % r) * r + (X % r);
+        if (!inverse) *at<T>(hi, phi, c) = *at<T>(lo, plo, clo);
+        else *((T*)lo.p + plo * lo.cs + lo.co + clo) = *((const T*)hi.p + phi * hi.cs + hi.co + c);
+    }
+}
+
+template <typename T>
+__global__ void relu_bwd_stats_kernel(Ref dout, Ref out, Ref y, const float* mean, const float* invstd, MRef dz, double* stats,
+                                      long npix, int c, ChanMap m) {
+    __shared__ float lds[TPB * 8];
+    float acc[2][4];
+    auto reset = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][e] = acc[1][e] = 0.f;
+    };
+    reset();
+    for_items(m, npix,
+        [&](long pix, int c0) {
+            float g[4], o[4], yv[4], mu[4], is[4];
+            load4(at<T>(dout, pix, c0), g); load4(at<T>(out, pix, c0), o); load4(at<T>(y, pix, c0), yv);
+            load4(mean + c0, mu); load4(invstd + c0, is);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[e] = o[e] > 0.f ? g[e] : 0.f;
+                acc[0][e] += g[e];
+                acc[1][e] += g[e] * (yv[e] - mu[e]) * is[e];
+            }
+            store4(at<T>(dz, pix, c0), g);
+        },
+        [&](int cg) { flush_sums<2>(m, cg, acc, stats, c, lds); reset(); });
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(Ref g, Ref y, const float* A, const float* B, const float* Cc, MRef dy, long npix, int c) {
+    const int cg = c / 4;
+    const long total = npix * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        const long pix = i / cg;
+        float gv[4], yv[4], a[4], b[4], cc[4], o[4];
+        load4(at<T>(g, pix, c0), gv); load4(at<T>(y, pix, c0), yv);
+        load4(A + c0, a); load4(B + c0, b); load4(Cc + c0, cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], gv[e], fmaf(b[e], yv[e], cc[e]));
+        store4(at<T>(dy, pix, c0), o);
+    }
+}
+
+template <typename T>
+__global__ void channel_sum_kernel(Ref x, double* out, long npix, int c, ChanMap m) {
+    __shared__ float lds[TPB * 4];
+    float acc[1][4] = {{0, 0, 0, 0}};
+    for_items(m, npix,
+        [&](long pix, int c0) {
+            float v[4];
+            load4(at<T>(x, pix, c0), v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
+        },
+        [&](int cg) { flush_sums<1>(m, cg, acc, out, c, lds); acc[0][0] = acc[0][1] = acc[0][2] = acc[0][3] = 0.f; });
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int n, int c, long hw, int cs, float scale) {
+    const long total = (long)n * hw * cs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % cs;
+        const long pix = i / cs;
+        const long img = pix / hw, p = pix % hw;
+        out[i] = (T)(k < c ? in[(img * c + k) * hw + p] * scale : 0.f);
+    }
+}
+
+__global__ void clip_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = fminf(fmaxf(in[i], 0.f), 255.f);
+        out[i] = (uint8_t)v;   // truncation toward zero, as numpy astype(uint8) on a clipped array
+    }
+}
+
+__global__ void f64_to_f32_kernel(const double* in, float* out, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = accumulate ? out[i] + (float)in[i] : (float)in[i];
+}
+
+static inline int grid1d(long total) { long b = (total + TPB - 1) / TPB; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                             \
+    do {                                                                    \
+        if ((dtype) == PSSR_BF16) { using T = bf16_t; CALL; }               \
+        else if ((dtype) == PSSR_F32) { using T = float; CALL; }            \
+        else { pssr_set_error("bad dtype %d", (dtype)); return PSSR_ERR_ARG; } \
+    } while (0)
+
+extern "C" {
+
+int pssr_channel_stats_nchw(const float* x, int n, int c, int64_t hw, float pre_scale, float pre_shift, double* stats, pssr_stream_t s) {
+    PSSR_CHECK(x && stats && n > 0 && c > 0 && hw > 0, PSSR_ERR_ARG, "channel_stats_nchw: bad args");
+    int chunks = (int)((hw + TPB * 8 - 1) / (TPB * 8));
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(nchw_stats_kernel, dim3(chunks, n * c), dim3(TPB), 0, (hipStream_t)s, x, n, c, (long)hw, pre_scale, pre_shift, stats);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, int c, pssr_stream_t s) {
+    PSSR_CHECK(stats && scale && shift && c > 0 && count > 0, PSSR_ERR_ARG, "bn_finalize: bad args");
+    PSSR_CHECK((running_mean == nullptr) == (running_var == nullptr), PSSR_ERR_ARG, "bn_finalize: running stats come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, (hipStream_t)s, stats, count, gamma, beta, eps, momentum,
+                       running_mean, running_var, scale, shift, mean, invstd, c);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                        float* scale, float* shift, int c, pssr_stream_t s) {
+    PSSR_CHECK(gamma && beta && running_mean && running_var && scale && shift && c > 0, PSSR_ERR_ARG, "bn_eval_affine: bad args");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, (hipStream_t)s, gamma, beta, running_mean, running_var, eps, scale, shift, c);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_bn_bwd_coefs(const double* stats, double count, const float* gamma, const float* mean, const float* invstd,
+                      float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta, int c, pssr_stream_t s) {
+    PSSR_CHECK(stats && gamma && mean && invstd && coef_a && coef_b && coef_c && c > 0 && count > 0, PSSR_ERR_ARG, "bn_bwd_coefs: bad args");
+    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, (hipStream_t)s, stats, count, gamma, mean, invstd,
+                       coef_a, coef_b, coef_c, dgamma, dbeta, c);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_input_im2col(const float* x, void* xcol, int n, int c, int h, int w, int xc, float pre_scale, float pre_shift,
+                      const float* scale, const float* shift, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(x && xcol && scale && shift && n > 0 && c > 0 && h > 0 && w > 0 && xc >= 9 * c && xc % 16 == 0, PSSR_ERR_ARG, "input_im2col: bad args");
+    const long total = (long)n * h * w * xc;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(input_im2col_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, x, (T*)xcol, n, c, h, w, xc,
+                                         pre_scale, pre_shift, scale, shift));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const float* x, float pre_scale, float pre_shift,
+                        const float* mean, const float* invstd, int n, int c, int h, int w, double* stats, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dxcol_a && x && mean && invstd && stats && xc >= 9 * c, PSSR_ERR_ARG, "input_norm_bwd: bad args");
+    const long total = (long)n * h * w;
+    int gx = (int)((total + TPB * 4 - 1) / (TPB * 4));
+    if (gx > 512) gx = 512;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(input_norm_bwd_kernel<T>, dim3(gx, c), dim3(TPB), 0, (hipStream_t)s, (const T*)dxcol_a, (const T*)dxcol_b, xc, x,
+                                         pre_scale, pre_shift, mean, invstd, n, c, h, w, stats));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+#define CHECK_REF(name, cs, co, c)                                                                               \
+    PSSR_CHECK((cs) % 4 == 0 && (co) % 4 == 0 && (co) + (c) <= (cs), PSSR_ERR_ARG, name ": bad channel stride/offset (%d,%d,%d)", cs, co, c)
+
+int pssr_maxpool2(const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co, int n, int h, int w, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0 && h > 1 && w > 1 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "maxpool2: bad args");
+    CHECK_REF("maxpool2 in", in_cs, in_co, c); CHECK_REF("maxpool2 out", out_cs, out_co, c);
+    const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co}, MRef{out, out_cs, out_co}, n, h, w, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_maxpool2_bwd(const void* act, int act_cs, int act_co, const void* dpool, int dp_cs, int dp_co,
+                      const void* dskip, int ds_cs, int ds_co, void* dout, int do_cs, int do_co,
+                      int n, int h, int w, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(act && dpool && dout && n > 0 && h > 1 && w > 1 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "maxpool2_bwd: bad args");
+    CHECK_REF("maxpool2_bwd act", act_cs, act_co, c); CHECK_REF("maxpool2_bwd dpool", dp_cs, dp_co, c); CHECK_REF("maxpool2_bwd dout", do_cs, do_co, c);
+    if (dskip) CHECK_REF("maxpool2_bwd dskip", ds_cs, ds_co, c);
+    const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, Ref{act, act_cs, act_co},
+                                         Ref{dpool, dp_cs, dp_co}, Ref{dskip, ds_cs, ds_co}, MRef{dout, do_cs, do_co}, n, h, w, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_pixel_shuffle(const void* lo, int lo_cs, int lo_co, void* hi, int hi_cs, int hi_co, int n, int h, int w, int c_hi, int r,
+                       int inverse, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(lo && hi && n > 0 && h > 0 && w > 0 && c_hi > 0 && r > 0, PSSR_ERR_ARG, "pixel_shuffle: bad args");
+    PSSR_CHECK(lo_co + c_hi * r * r <= lo_cs && hi_co + c_hi <= hi_cs, PSSR_ERR_ARG, "pixel_shuffle: slice exceeds stride");
+    const long total = (long)n * h * r * w * r * c_hi;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pixel_shuffle_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, Ref{lo, lo_cs, lo_co},
+                                         MRef{hi, hi_cs, hi_co}, n, h, w, c_hi, r, inverse));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out, int o_cs, int o_co, const void* y, int y_cs, int y_co,
+                        const float* mean, const float* invstd, void* dz, int dz_cs, int dz_co, double* stats,
+                        int64_t npix, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dout && out && y && mean && invstd && dz && stats && npix > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "relu_bwd_stats: bad args");
+    CHECK_REF("relu_bwd_stats dout", do_cs, do_co, c); CHECK_REF("relu_bwd_stats out", o_cs, o_co, c);
+    CHECK_REF("relu_bwd_stats y", y_cs, y_co, c); CHECK_REF("relu_bwd_stats dz", dz_cs, dz_co, c);
+    const ChanMap m = make_map(c);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(relu_bwd_stats_kernel<T>, dim3(grid_for(npix, m)), dim3(TPB), 0, (hipStream_t)s, Ref{dout, do_cs, do_co},
+                                         Ref{out, o_cs, o_co}, Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, (long)npix, c, m));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_bn_bwd_apply(const void* g, int g_cs, int g_co, const void* y, int y_cs, int y_co, const float* coef_a, const float* coef_b,
+                      const float* coef_c, void* dy, int dy_cs, int dy_co, int64_t npix, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(g && y && coef_a && coef_b && coef_c && dy && npix > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "bn_bwd_apply: bad args");
+    CHECK_REF("bn_bwd_apply g", g_cs, g_co, c); CHECK_REF("bn_bwd_apply y", y_cs, y_co, c); CHECK_REF("bn_bwd_apply dy", dy_cs, dy_co, c);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid1d(npix * (c / 4))), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co},
+                                         Ref{y, y_cs, y_co}, coef_a, coef_b, coef_c, MRef{dy, dy_cs, dy_co}, (long)npix, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_channel_sum_nhwc(const void* x, int cs, int co, int64_t npix, int c, double* out, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(x && out && npix > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "channel_sum: bad args");
+    CHECK_REF("channel_sum x", cs, co, c);
+    const ChanMap m = make_map(c);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, dim3(grid_for(npix, m)), dim3(TPB), 0, (hipStream_t)s, Ref{x, cs, co}, out, (long)npix, c, m));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_nchw_to_nhwc(const float* in, void* out, int n, int c, int64_t hw, int out_cs, float scale, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0 && c > 0 && hw > 0 && out_cs >= c, PSSR_ERR_ARG, "nchw_to_nhwc: bad args");
+    const long total = (long)n * hw * out_cs;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, in, (T*)out, n, c, (long)hw, out_cs, scale));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0, PSSR_ERR_ARG, "clip_u8: bad args");
+    hipLaunchKernelGGL(clip_u8_kernel, dim3(grid1d(n)), dim3(TPB), 0, (hipStream_t)s, in, out, (long)n);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0, PSSR_ERR_ARG, "f64_to_f32: bad args");
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)s, in, out, n, accumulate);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+}  // extern "C"

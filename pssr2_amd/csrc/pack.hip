@@ -19,10 +19,14 @@ struct PackMap {
             if (k >= cout || n >= ci_count) return -1;
             const int co = n_perm ? n_perm[k] : k;
             return ((long)co * cin + ci_begin + n) * kk + (kk - 1 - tap);
-        } else {                  // flat-K: K = (ci - ci_begin)*kk + tap', single tap
+        } else if (mode == 2) {   // flat-K: K = (ci - ci_begin)*kk + tap', single tap
             if (k >= ci_count * kk || n >= cout) return -1;
             const int co = n_perm ? n_perm[n] : n;
             return ((long)co * cin + ci_begin) * kk + k;
+        } else {                  // flat-K dgrad: K = co, N = (ci - ci_begin)*kk + tap', single tap
+            if (k >= cout || n >= ci_count * kk) return -1;
+            const int co = n_perm ? n_perm[k] : k;
+            return ((long)co * cin + ci_begin) * kk + n;
         }
     }
 };
@@ -66,13 +70,13 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
                                      int mode, const int32_t* n_perm, int k_pad, int n_pad, int dtype, pssr_stream_t stream) {
     PSSR_CHECK(w && packed, PSSR_ERR_ARG, "pack: null pointer");
     PSSR_CHECK(ks == 1 || ks == 3, PSSR_ERR_ARG, "pack: ks=%d", ks);
-    PSSR_CHECK(mode >= 0 && mode <= 2, PSSR_ERR_ARG, "pack: mode=%d", mode);
+    PSSR_CHECK(mode >= 0 && mode <= 3, PSSR_ERR_ARG, "pack: mode=%d", mode);
     PSSR_CHECK(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= cin, PSSR_ERR_ARG, "pack: channel range");
     PSSR_CHECK(k_pad % 16 == 0 && n_pad % 128 == 0, PSSR_ERR_ARG, "pack: k_pad=%d n_pad=%d", k_pad, n_pad);
-    const int gk = mode == 0 ? ci_count : mode == 1 ? cout : ci_count * ks * ks;
-    const int gn = mode == 1 ? ci_count : cout;
+    const int gk = mode == 0 ? ci_count : (mode == 1 || mode == 3) ? cout : ci_count * ks * ks;
+    const int gn = mode == 1 ? ci_count : mode == 3 ? ci_count * ks * ks : cout;
     PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
-    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode == 2 ? 1 : ks * ks, n_perm};
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
     const long total = (long)m.taps * k_pad * n_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == PSSR_BF16)

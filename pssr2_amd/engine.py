@@ -1,0 +1,449 @@
+"""Execution engine of the MI355X ResUNet: the whole forward and backward pass as an explicit
+sequence of libpssr_mi355.so launches over pre-allocated NHWC buffers.
+
+The reference runs ``ResUNet.forward`` (pssr/models/resunet.py:65-96) op by op through torch
+autograd.  Here one ``torch.autograd.Function`` covers the network: ``Engine.forward`` issues the
+fused kernels (conv + BatchNorm statistics epilogue, BatchNorm+ReLU prologue, residual tail, pool,
+pixel-shuffle into the concat buffer, two-source head, blocked-layout final conv) and keeps only the
+raw conv outputs; ``Engine.backward`` walks the same structure in reverse.  torch supplies device
+memory, the stream and the autograd hook — no torch operator computes on the hot path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1     # torch.nn.BatchNorm2d defaults used by the reference blocks
+
+
+def _log2(v: int) -> int:
+    l = int(math.log2(v))
+    if (1 << l) != v:
+        raise ValueError(f"the MI355X path needs a power-of-two upscaling factor, got scale={v}")
+    return l
+
+
+class _Arena:
+    """Bump allocator for the many small per-channel vectors (one memset zeroes all statistics)."""
+
+    def __init__(self):
+        self.req = []
+
+    def take(self, n):
+        self.req.append(n)
+        return len(self.req) - 1
+
+    def build(self, dtype, device):
+        offs, tot = [], 0
+        for n in self.req:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4
+        self.buf = torch.zeros(max(tot, 4), dtype=dtype, device=device)
+        self.views = [self.buf[o:o + n] for o, n in zip(offs, self.req)]
+        return self
+
+
+class _BNState:
+    def __init__(self, c, f32: _Arena, f64: _Arena):
+        self.c = c
+        self.i32 = [f32.take(c) for _ in range(7)]      # scale shift mean invstd coefA coefB coefC
+        self.i64 = [f64.take(2 * c) for _ in range(2)]  # forward stats, backward stats
+
+    def bind(self, f32: _Arena, f64: _Arena):
+        self.scale, self.shift, self.mean, self.invstd, self.ca, self.cb, self.cc = (f32.views[i] for i in self.i32)
+        self.stats, self.bstats = (f64.views[i] for i in self.i64)
+
+
+class _Conv:
+    """Packed-weight cache of one nn.Conv2d (re-packed only when the parameter version changes)."""
+
+    def __init__(self, module, specs):
+        self.m = module
+        self.specs = specs          # name -> dict(mode, ci_begin, ci_count, n_perm, w3x3_from_1x1)
+        self.packed = {}
+        self.version = {}
+
+    def weight_for(self, spec):
+        w = self.m.weight
+        if spec.get("center"):      # 1x1 weight consumed through the 3x3 im2col'ed input: centre tap only
+            w3 = torch.zeros(w.shape[0], w.shape[1], 3, 3, device=w.device, dtype=w.dtype)
+            w3[:, :, 1, 1] = w.detach()[:, :, 0, 0]
+            return w3
+        return w.detach()
+
+    def get(self, name, dtype):
+        spec = self.specs[name]
+        key = (name, dtype)
+        ver = self.m.weight._version
+        if self.version.get(key) != ver or key not in self.packed:
+            self.packed[key] = ops.pack_conv_weight(self.weight_for(spec).contiguous(), dtype, mode=spec["mode"],
+                                                    ci_begin=spec.get("ci_begin", 0), ci_count=spec.get("ci_count"),
+                                                    n_perm=spec.get("n_perm"), out=self.packed.get(key))
+            self.version[key] = ver
+        return self.packed[key]
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.plans = {}
+        self.saved = None
+        self._convs = {}
+
+    # ------------------------------------------------------------------ static structure
+    def _structure(self, device):
+        m = self.model
+        if getattr(self, "_built_for", None) == device:
+            return
+        self.cin, self.cout = m.channels
+        self.hidden = list(m.hidden)
+        self.L = len(self.hidden)
+        self.r = m.reconstruction.scale
+        self.blk = _log2(self.r)
+        self.xc = ops.pad_to(9 * self.cin, 16)
+        h0 = self.hidden[0]
+        r2 = self.r * self.r
+        # sub-pixel-major channel order of Reconstruction.pre: n' = sub*h0 + c  <-  n = c*r2 + sub
+        idx = torch.arange(r2 * h0)
+        self.pre_perm = ((idx % h0) * r2 + idx // h0).to(torch.int32).to(device)
+        self.pre_perm_long = self.pre_perm.long()
+        self._convs = {}
+        self._built_for = device
+
+    def _conv(self, module, **specs):
+        c = self._convs.get(id(module))
+        if c is None:
+            c = self._convs[id(module)] = _Conv(module, specs)
+        return c
+
+    def _check_supported(self, dtype_code, h, w, train):
+        kch = 16 if dtype_code == L.BF16 else 8
+        for i, hc in enumerate(self.hidden):
+            if hc % kch:
+                raise ValueError(f"hidden[{i}]={hc}: the MI355X path needs channel counts that are multiples of {kch} "
+                                 f"for compute dtype {'bf16' if dtype_code == L.BF16 else 'f32'}")
+            if i and hc % 16:
+                raise ValueError(f"hidden[{i}]={hc} must be a multiple of 16 (pixel-shuffle slice alignment)")
+        if h % (1 << (self.L - 1)) or w % (1 << (self.L - 1)):
+            raise ValueError(f"input size {h}x{w} must be divisible by 2^{self.L - 1} (max-pool / pixel-shuffle symmetry)")
+        if train and min(h, w) >> (self.L - 1) < 3:
+            raise ValueError("training needs at least 3x3 pixels at the deepest level on the MI355X path")
+
+    # ------------------------------------------------------------------ per-shape plan
+    def _plan(self, n, h, w, dt, device):
+        key = (n, h, w, dt, str(device))
+        p = self.plans.get(key)
+        if p is not None:
+            return p
+        code = ops.dtype_code(dt)
+        Lv, hid = self.L, self.hidden
+        p = type("Plan", (), {})()
+        p.n, p.h, p.w, p.dt, p.code = n, h, w, dt, code
+        p.dims = [(h >> i, w >> i) for i in range(Lv)]
+        f32, f64 = _Arena(), _Arena()
+        m = self.model
+
+        def buf(hh, ww, c):
+            return torch.zeros(n, hh, ww, ops.pad_to(c, 16), dtype=dt, device=device)
+
+        p.bn_in = _BNState(self.cin, f32, f64)
+        p.xcol = buf(h, w, self.xc)
+        p.enc, p.dec = [], []
+        nl = max(m.depth, 0) + 1
+        # concat buffers: cat[l] = [shuffle(level l+1 output) | encoder l output]
+        p.cat = [buf(*p.dims[l], hid[l + 1] // 4 + hid[l]) for l in range(Lv - 1)]
+        p.pooled = [buf(*p.dims[l + 1], hid[l]) for l in range(Lv - 1)]
+        for i in range(Lv):
+            b = type("B", (), {})()
+            b.level, b.c = i, hid[i]
+            b.y = [buf(*p.dims[i], hid[i]) for _ in range(nl)]
+            b.bn = [_BNState(hid[i], f32, f64) for _ in range(nl)]
+            b.out = None if i < Lv - 1 else buf(*p.dims[i], hid[i])       # encoder outputs live in cat[i]
+            p.enc.append(b)
+        for l in range(Lv - 1):
+            b = type("B", (), {})()
+            b.level, b.c = l, hid[l]
+            b.y = [buf(*p.dims[l], hid[l]) for _ in range(nl)]
+            b.bn = [_BNState(hid[l], f32, f64) for _ in range(nl)]
+            b.out = buf(*p.dims[l], hid[l])
+            p.dec.append(b)                                              # p.dec[l] is the block at level l
+        r2 = self.r * self.r
+        p.pre = torch.zeros(n, h, w, r2 * hid[0], dtype=dt, device=device)
+        p.f32 = f32.build(torch.float32, device)
+        p.f64 = f64.build(torch.float64, device)
+        p.bn_in.bind(f32, f64)
+        for b in p.enc + p.dec:
+            for s in b.bn:
+                s.bind(f32, f64)
+        p.ones_pre = torch.ones(r2 * hid[0], dtype=torch.float32, device=device)
+        p.zeros_pre = torch.zeros(r2 * hid[0], dtype=torch.float32, device=device)
+        p.bwd = None
+        self.plans[key] = p
+        return p
+
+    def _bwd_buffers(self, p, device):
+        if p.bwd is not None:
+            return p.bwd
+        n, dt, hid, Lv = p.n, p.dt, self.hidden, self.L
+        b = type("Bwd", (), {})()
+
+        def buf(hh, ww, c):
+            return torch.zeros(n, hh, ww, ops.pad_to(c, 16), dtype=dt, device=device)
+
+        b.dz = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
+        b.dy = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
+        b.g = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
+        b.dout = [buf(*p.dims[l], hid[l]) for l in range(Lv)]            # gradient of a block output at level l
+        b.dcat = [buf(*p.dims[l], hid[l + 1] // 4 + hid[l]) for l in range(Lv - 1)]
+        b.dpooled = [buf(*p.dims[l + 1], hid[l]) for l in range(Lv - 1)]
+        b.dxcol_a = buf(p.h, p.w, self.xc)
+        b.dxcol_b = buf(p.h, p.w, self.xc)
+        r = self.r
+        b.g_hr = torch.zeros(n, p.h * r, p.w * r, 16, dtype=dt, device=device)
+        b.dpre = torch.zeros(n, p.h, p.w, r * r * hid[0], dtype=dt, device=device)
+        b.sum64 = torch.zeros(max(16, r * r * hid[0]) + 2 * self.cin + 16, dtype=torch.float64, device=device)
+        p.bwd = b
+        return b
+
+    # ------------------------------------------------------------------ forward
+    def _bn_forward(self, p, st, bn_module, count, train):
+        if train:
+            ops.bn_finalize(st.stats, count, bn_module.weight, bn_module.bias, BN_EPS, BN_MOMENTUM,
+                            bn_module.running_mean, bn_module.running_var, st.scale, st.shift, st.mean, st.invstd)
+            bn_module.num_batches_tracked += 1
+        else:
+            ops.bn_eval_affine(bn_module.weight, bn_module.bias, bn_module.running_mean, bn_module.running_var, BN_EPS,
+                               st.scale, st.shift)
+
+    def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
+        n = p.n
+        hh, ww = p.dims[blk.level]
+        count = float(n * hh * ww)
+        nl = len(blk.y)
+        for k in range(nl):
+            conv = module.conv[3 * k]
+            bn = module.conv[3 * k + 1]
+            if k == 0:
+                if first:
+                    pw = self._conv(conv, fwd=dict(mode=2), dgrad=dict(mode=3)).get("fwd", p.code)
+                else:
+                    pw = self._conv(conv, fwd=dict(mode=0), dgrad=dict(mode=1)).get("fwd", p.code)
+                ops.conv2d(src, cin, pw, blk.y[0], blk.c, n=n, h=hh, w=ww, bias=conv.bias,
+                           flags=L.FLAG_STATS if train else 0, stats=blk.bn[0].stats if train else None)
+            else:
+                pw = self._conv(conv, fwd=dict(mode=0), dgrad=dict(mode=1)).get("fwd", p.code)
+                prev = blk.bn[k - 1]
+                ops.conv2d(blk.y[k - 1], blk.c, pw, blk.y[k], blk.c, n=n, h=hh, w=ww, bias=conv.bias,
+                           pro_scale=prev.scale, pro_shift=prev.shift,
+                           flags=L.FLAG_STATS if train else 0, stats=blk.bn[k].stats if train else None)
+            self._bn_forward(p, blk.bn[k], bn, count, train)
+        rp = module.respass
+        if first:
+            pw = self._conv(rp, fwd=dict(mode=2, center=True), dgrad=dict(mode=3, center=True)).get("fwd", p.code)
+        else:
+            pw = self._conv(rp, fwd=dict(mode=0), dgrad=dict(mode=1)).get("fwd", p.code)
+        last = blk.bn[-1]
+        ops.conv2d(src, cin, pw, dst, blk.c, n=n, h=hh, w=ww, out_coff=dst_coff, bias=rp.bias, epilogue=L.EPI_TAIL,
+                   aux=blk.y[-1], aux_scale=last.scale, aux_shift=last.shift)
+
+    def forward(self, x, train):
+        m = self.model
+        if not x.is_cuda:
+            raise RuntimeError("pssr2_amd.ResUNet runs on an MI355X (HIP) device only; there is no CPU fallback")
+        x = x.contiguous().float()
+        self._structure(x.device)
+        n, c, h, w = x.shape
+        if c != self.cin:
+            raise ValueError(f"expected {self.cin} input channels, got {c}")
+        dt = m.compute_dtype
+        code = ops.dtype_code(dt)
+        self._check_supported(code, h, w, train)
+        p = self._plan(n, h, w, dt, x.device)
+        Lv, hid = self.L, self.hidden
+        if train:
+            p.f64.buf.zero_()
+            ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
+        self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
+        ops.input_im2col(x, p.xcol, p.bn_in.scale, p.bn_in.shift, code)
+        # encoder
+        for i in range(Lv):
+            blk = p.enc[i]
+            src, cin = (p.xcol, self.xc) if i == 0 else (p.pooled[i - 1], ops.pad_to(hid[i - 1], 16))
+            if i < Lv - 1:
+                dst, off = p.cat[i], hid[i + 1] // 4
+            else:
+                dst, off = blk.out, 0
+            self._block_forward(p, blk, m.encoder[i], src, cin, i == 0, dst, off, train)
+            if i < Lv - 1:
+                ops.maxpool2(dst, p.pooled[i], n, *p.dims[i], hid[i], code, in_coff=off)
+        # decoder
+        for l in range(Lv - 2, -1, -1):
+            prev = p.enc[Lv - 1].out if l == Lv - 2 else p.dec[l + 1].out
+            ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
+            blk = p.dec[l]
+            self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train)
+        # head: relu(conv3x3([dec0 | x0])) in sub-pixel-major channel order == pixel-shuffled, blocked layout
+        rec = m.reconstruction
+        h0 = hid[0]
+        feat = p.dec[0].out if Lv > 1 else p.enc[0].out
+        cpre = self._conv(rec.pre,
+                          fwd0=dict(mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
+                          fwd1=dict(mode=2, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm),
+                          dgrad0=dict(mode=1, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
+                          dgrad1=dict(mode=3, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm))
+        p.pre_bias = rec.pre.bias.detach()[self.pre_perm_long].contiguous()
+        ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, self.r * self.r * h0, n=n, h=h, w=w, bias=p.pre_bias,
+                   x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)
+        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
+        out = torch.empty(n, self.cout, h * self.r, w * self.r, dtype=torch.float32, device=x.device)
+        pre_hr = p.pre.view(n, h * self.r, w * self.r, h0)
+        ops.conv2d(pre_hr, h0, cfin.get("fwd", code), out, self.cout, n=n, h=h * self.r, w=w * self.r, bias=rec.conv.bias,
+                   epilogue=L.EPI_FINAL, in0_blk=self.blk, out_scale=128.0, out_shift=128.0)
+        self.saved = (p, x) if train else None
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,
+               n_perm=None, pro=None, dy_blk=0, in_blk=0, hh, ww, center=False, dy_view_c=None):
+        code = p.code
+        esz = 2 if code == L.BF16 else 4
+        co_eff = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
+        dwp = torch.zeros(co_eff, taps, cin_pad, dtype=torch.float32, device=dy.device)
+        ops.conv2d_wgrad(dy, co_eff, src, cin_pad, taps, dwp, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
+                         pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)
+        w = conv_module.weight
+        gname = id(w)
+        if center:
+            g3 = torch.zeros(w.shape[0], w.shape[1], 3, 3, dtype=torch.float32, device=w.device)
+            ops.unpack_conv_wgrad(dwp, g3, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
+            grads[gname] = g3[:, :, 1:2, 1:2].contiguous()
+            return
+        if gname not in grads:
+            grads[gname] = torch.zeros_like(w, dtype=torch.float32)
+        ops.unpack_conv_wgrad(dwp, grads[gname], mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
+
+    def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
+        """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc."""
+        n, code = p.n, p.code
+        lvl = blk.level
+        hh, ww = p.dims[lvl]
+        npix = n * hh * ww
+        count = float(npix)
+        nl = len(blk.y)
+        dz, dy, g = bw.dz[lvl], bw.dy[lvl], bw.g[lvl]
+        last = blk.bn[-1]
+        bn_last = module.conv[3 * (nl - 1) + 1]
+        ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
+        dgam = torch.empty_like(bn_last.weight)
+        dbet = torch.empty_like(bn_last.bias)
+        ops.bn_bwd_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
+        grads[id(bn_last.weight)], grads[id(bn_last.bias)] = dgam, dbet
+        grads[id(module.respass.bias)] = dbet.clone()       # d(respass bias) = sum dz = dbeta of the last BN
+        ops.bn_bwd_apply(dz, blk.y[-1], last.ca, last.cb, last.cc, dy, npix, blk.c, code)
+        for k in range(nl - 1, 0, -1):
+            conv = module.conv[3 * k]
+            prev, bn_prev = blk.bn[k - 1], module.conv[3 * (k - 1) + 1]
+            grads[id(conv.bias)] = torch.zeros_like(conv.bias)     # bias in front of a batch-stat BN: exactly zero
+            self._wgrad(p, grads, conv, dy, blk.c, blk.y[k - 1], blk.c, 9, pro=prev, hh=hh, ww=ww)
+            pwd = self._conv(conv, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
+            ops.conv2d(dy, blk.c, pwd, g, blk.c, n=n, h=hh, w=ww, epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS,
+                       aux=blk.y[k - 1], aux_scale=prev.scale, aux_shift=prev.shift, aux_mean=prev.mean, aux_invstd=prev.invstd,
+                       stats=prev.bstats)
+            dgam, dbet = torch.empty_like(bn_prev.weight), torch.empty_like(bn_prev.bias)
+            ops.bn_bwd_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
+            grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
+            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy, npix, blk.c, code)
+        conv0, rp = module.conv[0], module.respass
+        grads[id(conv0.bias)] = torch.zeros_like(conv0.bias)
+        if first:
+            self._wgrad(p, grads, conv0, dy, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww)
+            self._wgrad(p, grads, rp, dz, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww, center=True)
+            c0 = self._conv(conv0, fwd=dict(mode=2), dgrad=dict(mode=3)).get("dgrad", code)
+            c1 = self._conv(rp, fwd=dict(mode=2, center=True), dgrad=dict(mode=3, center=True)).get("dgrad", code)
+        else:
+            self._wgrad(p, grads, conv0, dy, blk.c, src, cin, 9, hh=hh, ww=ww)
+            self._wgrad(p, grads, rp, dz, blk.c, src, cin, 1, hh=hh, ww=ww)
+            c0 = self._conv(conv0, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
+            c1 = self._conv(rp, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
+        ops.conv2d(dy, blk.c, c0, dsrc, dsrc_c, n=n, h=hh, w=ww, x1=dz, cin1=blk.c, w1=c1)
+
+    def backward(self, dout):
+        if self.saved is None:
+            raise RuntimeError("backward called without a training-mode forward (or called twice)")
+        p, x = self.saved
+        self.saved = None
+        m = self.model
+        dev = x.device
+        bw = self._bwd_buffers(p, dev)
+        n, h, w, code = p.n, p.h, p.w, p.code
+        Lv, hid, r = self.L, self.hidden, self.r
+        h0 = hid[0]
+        grads = {}
+        rec = m.reconstruction
+        H, W = h * r, w * r
+        dout = dout.contiguous().float()
+        # ---- final conv (x*128+128 folded into the incoming gradient)
+        ops.nchw_to_nhwc(dout, bw.g_hr, 128.0, code)
+        bw.sum64.zero_()
+        ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
+        gb = torch.empty(16, dtype=torch.float32, device=dev)
+        ops.f64_to_f32(bw.sum64[:16], gb)
+        grads[id(rec.conv.bias)] = gb[:self.cout].clone()
+        pre_hr = p.pre.view(n, H, W, h0)
+        self._wgrad(p, grads, rec.conv, bw.g_hr, 16, pre_hr, h0, 9, in_blk=self.blk, hh=H, ww=W)
+        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
+        dpre_hr = bw.dpre.view(n, H, W, h0)
+        ops.conv2d(bw.g_hr, 16, cfin.get("dgrad", code), dpre_hr, h0, n=n, h=H, w=W, epilogue=L.EPI_DGRAD_MASK,
+                   aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
+        # ---- Reconstruction.pre (two sources)
+        cpre_n = r * r * h0
+        bw.sum64.zero_()
+        ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
+        gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
+        ops.f64_to_f32(bw.sum64[:cpre_n], gpb)
+        gb_pre = torch.empty_like(gpb)
+        gb_pre[self.pre_perm_long] = gpb
+        grads[id(rec.pre.bias)] = gb_pre
+        feat = p.dec[0].out if Lv > 1 else p.enc[0].out
+        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
+        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
+                    n_perm=self.pre_perm, hh=h, ww=w)
+        cpre = self._convs[id(rec.pre)]
+        dfeat = bw.dout[0]
+        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
+        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
+        # ---- decoder, bottom-up in the data-flow sense (level 0 first)
+        for l in range(0, Lv - 1):
+            blk = p.dec[l]
+            self._block_backward(p, bw, grads, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False,
+                                 blk.out, 0, bw.dout[l], bw.dcat[l], hid[l + 1] // 4 + hid[l])
+            # split dcat: [0, h_{l+1}/4) -> un-shuffle to the producer at level l+1
+            ops.pixel_shuffle(bw.dout[l + 1], bw.dcat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code, inverse=True)
+        # ---- encoder, deepest first
+        for i in range(Lv - 1, -1, -1):
+            blk = p.enc[i]
+            if i < Lv - 1:
+                off = hid[i + 1] // 4
+                # block output feeds the pool (dpooled) and the skip (dcat slice)
+                ops.maxpool2_bwd(p.cat[i], bw.dpooled[i], bw.dcat[i], bw.dout[i], n, *p.dims[i], hid[i], code,
+                                 act_coff=off, dskip_coff=off)
+                out_buf, out_off = p.cat[i], off
+            else:
+                out_buf, out_off = blk.out, 0
+            if i == 0:
+                src, cin, dsrc, dsrc_c = p.xcol, self.xc, bw.dxcol_a, self.xc
+            else:
+                src, cin, dsrc, dsrc_c = p.pooled[i - 1], ops.pad_to(hid[i - 1], 16), bw.dpooled[i - 1], hid[i - 1]
+            self._block_backward(p, bw, grads, blk, m.encoder[i], src, cin, i == 0, out_buf, out_off, bw.dout[i], dsrc, dsrc_c)
+        # ---- input BatchNorm parameters
+        st = p.bn_in
+        st.bstats.zero_()
+        ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
+        dgam, dbet = torch.empty_like(m.norm.weight), torch.empty_like(m.norm.bias)
+        ops.bn_bwd_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
+        grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
+        return grads

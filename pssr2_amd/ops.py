@@ -36,13 +36,13 @@ class PackedWeight:
 
 def pack_conv_weight(w: torch.Tensor, dtype: int, mode: int = 0, ci_begin: int = 0, ci_count: int | None = None,
                      n_perm: torch.Tensor | None = None, out: PackedWeight | None = None) -> PackedWeight:
-    """OIHW f32 -> packed (mode 0 forward, 1 dgrad, 2 flat-K im2col)."""
+    """OIHW f32 -> packed (mode 0 forward, 1 dgrad, 2 flat-K im2col, 3 flat-K dgrad)."""
     assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
     cout, cin, ks, _ = w.shape
     ci_count = cin - ci_begin if ci_count is None else ci_count
-    gk = ci_count if mode == 0 else cout if mode == 1 else ci_count * ks * ks
-    gn = ci_count if mode == 1 else cout
-    taps = 1 if mode == 2 else ks * ks
+    gk = ci_count if mode == 0 else cout if mode in (1, 3) else ci_count * ks * ks
+    gn = ci_count if mode == 1 else ci_count * ks * ks if mode == 3 else cout
+    taps = 1 if mode >= 2 else ks * ks
     k_pad, n_pad = pad_to(gk, 16), pad_to(gn, 128)
     if out is None:
         nbytes = L.lib().pssr_packed_weight_bytes(taps, k_pad, n_pad, dtype)
@@ -102,3 +102,91 @@ def unpack_conv_wgrad(dw_packed, dw_oihw, *, mode=0, ci_begin=0, ci_count=None, 
     L.check(L.lib().pssr_unpack_conv_wgrad(L.ptr(dw_packed), L.ptr(dw_oihw), cout, cin, ks, ci_begin, ci_count, mode,
                                            L.ptr(n_perm), k_pad, int(accumulate), L.stream_ptr()), "pssr_unpack_conv_wgrad")
     return dw_oihw
+
+
+# ----------------------------------------------------------------------------------------------
+# per-channel / pointwise kernels (csrc/elementwise.hip)
+def _ref(t, coff=0):
+    return L.ptr(t), t.shape[-1], coff
+
+
+def channel_stats_nchw(x, stats, pre_scale=1.0, pre_shift=0.0):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_channel_stats_nchw(L.ptr(x), n, c, C.c_int64(h * w), C.c_float(pre_scale), C.c_float(pre_shift),
+                                            L.ptr(stats), L.stream_ptr()), "pssr_channel_stats_nchw")
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd):
+    c = scale.numel()
+    L.check(L.lib().pssr_bn_finalize(L.ptr(stats), C.c_double(count), L.ptr(gamma), L.ptr(beta), C.c_float(eps), C.c_float(momentum),
+                                     L.ptr(running_mean), L.ptr(running_var), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
+                                     c, L.stream_ptr()), "pssr_bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
+    L.check(L.lib().pssr_bn_eval_affine(L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), C.c_float(eps),
+                                        L.ptr(scale), L.ptr(shift), scale.numel(), L.stream_ptr()), "pssr_bn_eval_affine")
+
+
+def bn_bwd_coefs(stats, count, gamma, mean, invstd, coef_a, coef_b, coef_c, dgamma, dbeta):
+    L.check(L.lib().pssr_bn_bwd_coefs(L.ptr(stats), C.c_double(count), L.ptr(gamma), L.ptr(mean), L.ptr(invstd), L.ptr(coef_a),
+                                      L.ptr(coef_b), L.ptr(coef_c), L.ptr(dgamma), L.ptr(dbeta), coef_a.numel(), L.stream_ptr()),
+            "pssr_bn_bwd_coefs")
+
+
+def bn_bwd_apply(g, y, coef_a, coef_b, coef_c, dy, npix, c, dtype, g_coff=0, y_coff=0, dy_coff=0):
+    L.check(L.lib().pssr_bn_bwd_apply(*_ref(g, g_coff), *_ref(y, y_coff), L.ptr(coef_a), L.ptr(coef_b), L.ptr(coef_c),
+                                      *_ref(dy, dy_coff), C.c_int64(npix), c, dtype, L.stream_ptr()), "pssr_bn_bwd_apply")
+
+
+def input_im2col(x, xcol, scale, shift, dtype, pre_scale=1 / 128, pre_shift=-1.0):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_input_im2col(L.ptr(x), L.ptr(xcol), n, c, h, w, xcol.shape[-1], C.c_float(pre_scale), C.c_float(pre_shift),
+                                      L.ptr(scale), L.ptr(shift), dtype, L.stream_ptr()), "pssr_input_im2col")
+
+
+def input_norm_bwd(dxcol_a, dxcol_b, x, mean, invstd, stats, dtype, pre_scale=1 / 128, pre_shift=-1.0):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_input_norm_bwd(L.ptr(dxcol_a), L.ptr(dxcol_b), dxcol_a.shape[-1], L.ptr(x), C.c_float(pre_scale),
+                                        C.c_float(pre_shift), L.ptr(mean), L.ptr(invstd), n, c, h, w, L.ptr(stats), dtype,
+                                        L.stream_ptr()), "pssr_input_norm_bwd")
+
+
+def maxpool2(x, out, n, h, w, c, dtype, in_coff=0, out_coff=0):
+    L.check(L.lib().pssr_maxpool2(*_ref(x, in_coff), *_ref(out, out_coff), n, h, w, c, dtype, L.stream_ptr()), "pssr_maxpool2")
+
+
+def maxpool2_bwd(act, dpool, dskip, dout, n, h, w, c, dtype, act_coff=0, dskip_coff=0):
+    ds = _ref(dskip, dskip_coff) if dskip is not None else (None, 0, 0)
+    L.check(L.lib().pssr_maxpool2_bwd(*_ref(act, act_coff), *_ref(dpool), *ds, *_ref(dout), n, h, w, c, dtype, L.stream_ptr()),
+            "pssr_maxpool2_bwd")
+
+
+def pixel_shuffle(lo, hi, n, h, w, c_hi, r, dtype, lo_coff=0, hi_coff=0, inverse=False):
+    L.check(L.lib().pssr_pixel_shuffle(*_ref(lo, lo_coff), *_ref(hi, hi_coff), n, h, w, c_hi, r, int(inverse), dtype,
+                                       L.stream_ptr()), "pssr_pixel_shuffle")
+
+
+def relu_bwd_stats(dout, out, y, mean, invstd, dz, stats, npix, c, dtype, out_coff=0):
+    L.check(L.lib().pssr_relu_bwd_stats(*_ref(dout), *_ref(out, out_coff), *_ref(y), L.ptr(mean), L.ptr(invstd), *_ref(dz),
+                                        L.ptr(stats), C.c_int64(npix), c, dtype, L.stream_ptr()), "pssr_relu_bwd_stats")
+
+
+def channel_sum_nhwc(x, npix, c, out, dtype, coff=0, cstride=None):
+    cs = x.shape[-1] if cstride is None else cstride
+    L.check(L.lib().pssr_channel_sum_nhwc(L.ptr(x), cs, coff, C.c_int64(npix), c, L.ptr(out), dtype, L.stream_ptr()),
+            "pssr_channel_sum_nhwc")
+
+
+def nchw_to_nhwc(x, out, scale, dtype):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_nchw_to_nhwc(L.ptr(x), L.ptr(out), n, c, C.c_int64(h * w), out.shape[-1], C.c_float(scale), dtype,
+                                      L.stream_ptr()), "pssr_nchw_to_nhwc")
+
+
+def clip_u8(x, out):
+    L.check(L.lib().pssr_clip_u8(L.ptr(x), L.ptr(out), C.c_int64(x.numel()), L.stream_ptr()), "pssr_clip_u8")
+
+
+def f64_to_f32(src, dst, accumulate=False):
+    L.check(L.lib().pssr_f64_to_f32(L.ptr(src), L.ptr(dst), dst.numel(), int(accumulate), L.stream_ptr()), "pssr_f64_to_f32")
