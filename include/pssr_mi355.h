@@ -196,6 +196,35 @@ int pssr_nchw_to_nhwc(const float* in, void* out, int n, int c, int64_t hw, int 
 int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t stream);
 int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, pssr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SSIM / MS-SSIM + Gaussian-L1 loss (pssr/util.py:10-52; pytorch_msssim 1.0.0 algorithm) on f32
+ * NCHW planes [planes = N*C][h][w].  `win_host` is a HOST array of k (odd, <= 33) filter taps.
+ * One level forward: sums[plane*2+0] += sum of the cs map, sums[plane*2+1] += sum of the ssim map
+ * over the (h-k+1)x(w-k+1) valid region; optional l1_sum += sum_q |x-y|(q) * S(q), S = zero-padded
+ * window mass (the mean over the padded G (*) |x-y| map of pssr/util.py:50 without materialising it). */
+int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w, const float* win_host,
+                        int k, float c1, float c2, double* sums, double* l1_sum, pssr_stream_t stream);
+/* F.avg_pool2d(kernel 2, padding = size % 2) between MS-SSIM levels */
+int pssr_avgpool2_planes(const float* in, float* out, int planes, int h, int w, pssr_stream_t stream);
+/* loss value and the per-plane, per-level upstream weights of the map elements (device side, no
+ * host sync): ms=1 -> prod_l relu(v_l)^w_l with v_l = cs mean (ssim mean at the last level);
+ * ms=0 -> plain SSIM mean.  loss = mix*(1-mean) + (1-mix)*l1 (l1_sum may be NULL when mix == 1). */
+int pssr_msssim_weights(const double* sums, int levels, int planes, const double* nvalid,
+                        const float* level_weights, int ms, float mix, const double* l1_sum,
+                        double l1_numel, const float* grad_out, float* loss_out, float* wts,
+                        float* l1_coef, pssr_stream_t stream);
+/* gradient of one level wrt x: transposed Gaussian filtering of the three adjoint maps, plus the
+ * avg-pool gradient from the coarser level (dcoarse, may be NULL) and the L1 term (l1_coef, device
+ * scalar, may be NULL). */
+int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w, const float* win_host,
+                        int k, float c1, float c2, const float* wts, int use_ssim, const float* dcoarse,
+                        int hc, int wc, const float* l1_coef, float* dx, pssr_stream_t stream);
+
+/* torch.optim.AdamW step (decoupled weight decay) over flat f32 buffers; `step` is 1-based. */
+int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                    pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

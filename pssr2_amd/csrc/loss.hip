@@ -1,0 +1,338 @@
+// SSIM / MS-SSIM + Gaussian-weighted L1 loss (pssr/util.py:10-52 -> pytorch_msssim), forward and
+// backward, on f32 NCHW planes.  HBM-bound: every level reads its two maps once per pass; the five
+// Gaussian-filtered maps (mu_x, mu_y, E[x^2], E[y^2], E[xy]) exist only in LDS.
+//
+// forward  (per level): tile of TS x TS *valid* positions; separable 11-tap filter through LDS;
+//                       per-plane f64 sums of the cs map and the ssim map (+ weighted |x-y| at level 0).
+// weights  (tiny)     : loss value and d loss / d(map element) per plane and level, on device.
+// backward (per level): recompute the filtered maps on a (TS+10)^2 halo, form the three adjoint maps
+//                       (wrt mu_x, E[x^2], E[xy]), apply the transposed filter, add the avg-pool
+//                       gradient arriving from the coarser level and the L1 term.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 32;       // tile side
+constexpr int MAXW = 33;     // largest supported window
+
+struct Win { float g[MAXW]; int k; };
+
+// ------------------------------------------------------------------------------------------------
+template <int K_DUMMY>
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                       Win win, float C1, float C2, double* sums /*[planes][2]*/,
+                                                       double* l1_sum /*nullable*/) {
+    // LDS: xs, ys [(TS+k-1)^2]; hp [5][(TS+k-1)][TS]
+    extern __shared__ float lds[];
+    const int k = win.k, halo = k - 1, IN = TS + halo;
+    float* xs = lds;
+    float* ys = xs + IN * IN;
+    float* hp = ys + IN * IN;
+    const int plane = blockIdx.z;
+    const int oy0 = blockIdx.y * TS, ox0 = blockIdx.x * TS;       // valid-map tile origin == input origin
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const int tid = threadIdx.x;
+    float l1 = 0.f;
+    for (int i = tid; i < IN * IN; i += 256) {
+        const int r = i / IN, c = i % IN;
+        const int gy = oy0 + r, gx = ox0 + c;
+        float xv = 0.f, yv = 0.f;
+        if (gy < H && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        xs[i] = xv; ys[i] = yv;
+    }
+    if (l1_sum) {
+        // L1 term: each pixel once (tiles partition the image when extended to cover it; see launcher)
+        const int ly0 = blockIdx.y * TS, lx0 = blockIdx.x * TS;
+        const int r5 = k / 2;
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int gy = ly0 + i / TS, gx = lx0 + i % TS;
+            if (gy < H && gx < W) {
+                float sy = 0.f, sx = 0.f;
+                for (int t = 0; t < k; ++t) {
+                    const int yy = gy + t - r5, xx = gx + t - r5;
+                    if (yy >= 0 && yy < H) sy += win.g[t];
+                    if (xx >= 0 && xx < W) sx += win.g[t];
+                }
+                l1 += fabsf(xp[(long)gy * W + gx] - yp[(long)gy * W + gx]) * sy * sx;
+            }
+        }
+    }
+    __syncthreads();
+    // horizontal pass: rows 0..IN-1, cols 0..TS-1
+    for (int i = tid; i < IN * TS; i += 256) {
+        const int r = i / TS, c = i % TS;
+        float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+        for (int t = 0; t < k; ++t) {
+            const float a = xs[r * IN + c + t], b = ys[r * IN + c + t], gw = win.g[t];
+            mx = fmaf(gw, a, mx); my = fmaf(gw, b, my);
+            xx = fmaf(gw, a * a, xx); yy = fmaf(gw, b * b, yy); xy = fmaf(gw, a * b, xy);
+        }
+        hp[0 * IN * TS + i] = mx; hp[1 * IN * TS + i] = my; hp[2 * IN * TS + i] = xx; hp[3 * IN * TS + i] = yy; hp[4 * IN * TS + i] = xy;
+    }
+    __syncthreads();
+    float cs_acc = 0.f, ss_acc = 0.f;
+    for (int i = tid; i < TS * TS; i += 256) {
+        const int r = i / TS, c = i % TS;
+        if (oy0 + r >= VH || ox0 + c >= VW) continue;
+        float m[5] = {0, 0, 0, 0, 0};
+        for (int t = 0; t < k; ++t) {
+            const float gw = win.g[t];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m[q] = fmaf(gw, hp[q * IN * TS + (r + t) * TS + c], m[q]);
+        }
+        const float mx = m[0], my = m[1];
+        const float sxx = m[2] - mx * mx, syy = m[3] - my * my, sxy = m[4] - mx * my;
+        const float cs = (2.f * sxy + C2) / (sxx + syy + C2);
+        const float lum = (2.f * mx * my + C1) / (mx * mx + my * my + C1);
+        cs_acc += cs; ss_acc += lum * cs;
+    }
+    __shared__ float red[3][256];
+    red[0][tid] = cs_acc; red[1][tid] = ss_acc; red[2][tid] = l1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(sums + plane * 2, (double)red[0][0]);
+        atomicAdd(sums + plane * 2 + 1, (double)red[1][0]);
+        if (l1_sum) atomicAdd(l1_sum, (double)red[2][0]);
+    }
+}
+
+// avg_pool2d(kernel 2, stride 2, padding = size % 2, count_include_pad) on planes
+__global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W, int HO, int WO) {
+    const int py = H & 1, px = W & 1;
+    const long total = (long)planes * HO * WO;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = i % WO, oy = (i / WO) % HO;
+        const long pl = i / ((long)WO * HO);
+        const float* src = in + pl * H * W;
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int y = 2 * oy - py + dy, x = 2 * ox - px + dx;
+                if (y >= 0 && y < H && x >= 0 && x < W) s += src[(long)y * W + x];
+            }
+        out[i] = 0.25f * s;
+    }
+}
+
+// loss and upstream weights.  sums: [levels][planes][2] (cs sum, ssim sum); nvalid[l] = valid positions per plane.
+__global__ void weights_kernel(const double* sums, int levels, int planes, const double* nvalid, const float* lvl_w, int ms,
+                               float mix, const double* l1_sum, double l1_numel, const float* grad_out,
+                               float* loss_out, float* wts /*[levels][planes]*/, float* l1_coef) {
+    __shared__ double acc[256];
+    const int tid = threadIdx.x;
+    const float go = grad_out ? grad_out[0] : 1.f;
+    double local = 0.0;
+    for (int p = tid; p < planes; p += 256) {
+        if (ms) {
+            double prod = 1.0;
+            double v[8];
+            for (int l = 0; l < levels; ++l) {
+                const double mean = sums[((long)l * planes + p) * 2 + (l == levels - 1 ? 1 : 0)] / nvalid[l];
+                v[l] = mean > 0 ? mean : 0.0;
+                prod *= pow(v[l], (double)lvl_w[l]);
+            }
+            local += prod;
+            for (int l = 0; l < levels; ++l) {
+                // d loss / d v_l = -mix/planes * w_l * prod / v_l ; spread over nvalid[l] map elements
+                const double d = v[l] > 0 ? -(double)mix / planes * lvl_w[l] * prod / v[l] : 0.0;
+                wts[(long)l * planes + p] = (float)(d / nvalid[l] * go);
+            }
+        } else {
+            const double mean = sums[(long)p * 2 + 1] / nvalid[0];
+            local += mean;      // nonnegative_ssim=False: no relu on plain SSIM
+            wts[p] = (float)(-(double)mix / planes / nvalid[0] * go);
+        }
+    }
+    acc[tid] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) acc[tid] += acc[tid + o]; __syncthreads(); }
+    if (tid == 0) {
+        double loss = mix * (1.0 - acc[0] / planes);
+        double lc = 0.0;
+        if (l1_sum) { loss = loss + (1.0 - mix) * l1_sum[0] / l1_numel; lc = (1.0 - mix) / l1_numel * go; }
+        else loss = (1.0 - acc[0] / planes);          // mix == 1: the reference skips the L1 branch entirely
+        loss_out[0] = (float)loss;
+        l1_coef[0] = (float)lc;
+    }
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, int H, int W, Win win,
+                                                       float C1, float C2, const float* __restrict__ wts /*[planes]*/, int use_ssim,
+                                                       const float* __restrict__ dcoarse, int HC, int WC,
+                                                       const float* l1_coef_p, float* __restrict__ dX) {
+    // output tile: TS x TS pixels at (qy0, qx0); adjoint maps needed at valid positions p in [q0-halo, q0+TS-1]
+    extern __shared__ float lds[];
+    const int k = win.k, halo = k - 1, AD = TS + halo, IN = TS + 2 * halo;
+    float* xs = lds;                       // [IN][IN]
+    float* ys = xs + IN * IN;              // [IN][IN]
+    float* hp = ys + IN * IN;              // [5][IN][AD]  (horizontal pass)  -> later reused for adjoint h-pass [3][AD][TS]
+    float* ad = hp + 5 * IN * AD;          // [3][AD][AD]  adjoint maps a, b, c
+    const int plane = blockIdx.z;
+    const int qy0 = blockIdx.y * TS, qx0 = blockIdx.x * TS;
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const int tid = threadIdx.x;
+    const float wt = wts[plane];
+    // inputs rows [qy0-halo, qy0+TS+halo)
+    for (int i = tid; i < IN * IN; i += 256) {
+        const int r = i / IN, c = i % IN;
+        const int gy = qy0 - halo + r, gx = qx0 - halo + c;
+        float xv = 0.f, yv = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        xs[i] = xv; ys[i] = yv;
+    }
+    __syncthreads();
+    for (int i = tid; i < IN * AD; i += 256) {
+        const int r = i / AD, c = i % AD;
+        float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+        for (int t = 0; t < k; ++t) {
+            const float a = xs[r * IN + c + t], b = ys[r * IN + c + t], gw = win.g[t];
+            mx = fmaf(gw, a, mx); my = fmaf(gw, b, my);
+            xx = fmaf(gw, a * a, xx); yy = fmaf(gw, b * b, yy); xy = fmaf(gw, a * b, xy);
+        }
+        hp[0 * IN * AD + i] = mx; hp[1 * IN * AD + i] = my; hp[2 * IN * AD + i] = xx; hp[3 * IN * AD + i] = yy; hp[4 * IN * AD + i] = xy;
+    }
+    __syncthreads();
+    for (int i = tid; i < AD * AD; i += 256) {
+        const int r = i / AD, c = i % AD;
+        const int py = qy0 - halo + r, px = qx0 - halo + c;     // valid-map position
+        float a = 0.f, b = 0.f, cc = 0.f;
+        if (py >= 0 && py < VH && px >= 0 && px < VW) {
+            float m[5] = {0, 0, 0, 0, 0};
+            for (int t = 0; t < k; ++t) {
+                const float gw = win.g[t];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] = fmaf(gw, hp[q * IN * AD + (r + t) * AD + c], m[q]);
+            }
+            const float mx = m[0], my = m[1];
+            const float sxx = m[2] - mx * mx, syy = m[3] - my * my, sxy = m[4] - mx * my;
+            const float Dcs = sxx + syy + C2, cs = (2.f * sxy + C2) / Dcs;
+            const float dcs_dmx = 2.f * (cs * mx - my) / Dcs, dcs_dexx = -cs / Dcs, dcs_dexy = 2.f / Dcs;
+            if (use_ssim) {
+                const float Dl = mx * mx + my * my + C1, lum = (2.f * mx * my + C1) / Dl;
+                const float dl_dmx = 2.f * (my - lum * mx) / Dl;
+                a = wt * (lum * dcs_dmx + cs * dl_dmx); b = wt * lum * dcs_dexx; cc = wt * lum * dcs_dexy;
+            } else {
+                a = wt * dcs_dmx; b = wt * dcs_dexx; cc = wt * dcs_dexy;
+            }
+        }
+        ad[0 * AD * AD + i] = a; ad[1 * AD * AD + i] = b; ad[2 * AD * AD + i] = cc;
+    }
+    __syncthreads();
+    // transposed filter, horizontal: out col q gets sum_t g[t] * ad[.., q + halo - t]  (ad col index = p - (q0-halo))
+    float* th = hp;                        // [3][AD][TS]
+    for (int i = tid; i < AD * TS; i += 256) {
+        const int r = i / TS, c = i % TS;
+        float s0 = 0, s1 = 0, s2 = 0;
+        for (int t = 0; t < k; ++t) {
+            const float gw = win.g[t];
+            const int src = r * AD + c + halo - t;
+            s0 = fmaf(gw, ad[src], s0); s1 = fmaf(gw, ad[AD * AD + src], s1); s2 = fmaf(gw, ad[2 * AD * AD + src], s2);
+        }
+        th[i] = s0; th[AD * TS + i] = s1; th[2 * AD * TS + i] = s2;
+    }
+    __syncthreads();
+    const float l1c = l1_coef_p ? l1_coef_p[0] : 0.f;
+    const int r5 = k / 2;
+    float* dxp = dX + (long)plane * H * W;
+    for (int i = tid; i < TS * TS; i += 256) {
+        const int r = i / TS, c = i % TS;
+        const int gy = qy0 + r, gx = qx0 + c;
+        if (gy >= H || gx >= W) continue;
+        float s0 = 0, s1 = 0, s2 = 0;
+        for (int t = 0; t < k; ++t) {
+            const float gw = win.g[t];
+            const int src = (r + halo - t) * TS + c;
+            s0 = fmaf(gw, th[src], s0); s1 = fmaf(gw, th[AD * TS + src], s1); s2 = fmaf(gw, th[2 * AD * TS + src], s2);
+        }
+        const float xv = xs[(r + halo) * IN + c + halo], yv = ys[(r + halo) * IN + c + halo];
+        float g = s0 + 2.f * xv * s1 + yv * s2;
+        if (dcoarse) {
+            const int cy = (gy + (H & 1)) >> 1, cx = (gx + (W & 1)) >> 1;
+            g += 0.25f * dcoarse[((long)plane * HC + cy) * WC + cx];
+        }
+        if (l1c != 0.f) {
+            float sy = 0.f, sx = 0.f;
+            for (int t = 0; t < k; ++t) {
+                const int yy = gy + t - r5, xx = gx + t - r5;
+                if (yy >= 0 && yy < H) sy += win.g[t];
+                if (xx >= 0 && xx < W) sx += win.g[t];
+            }
+            const float d = xv - yv;
+            g += l1c * sy * sx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        dxp[(long)gy * W + gx] = g;
+    }
+}
+
+Win make_win(const float* g, int k) {
+    Win w; w.k = k;
+    for (int i = 0; i < MAXW; ++i) w.g[i] = i < k ? g[i] : 0.f;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k,
+                        float c1, float c2, double* sums, double* l1_sum, pssr_stream_t s) {
+    PSSR_CHECK(x && y && sums && win_host && planes > 0 && k > 0 && k <= MAXW && (k & 1), PSSR_ERR_ARG, "ssim_level_fwd: bad args");
+    PSSR_CHECK(h >= k && w >= k, PSSR_ERR_ARG, "ssim_level_fwd: image %dx%d smaller than window %d", h, w, k);
+    const int IN = TS + k - 1;
+    const size_t lds = (size_t)(2 * IN * IN + 5 * IN * TS) * sizeof(float);
+    // when the L1 term is requested the tiles must cover the whole image, not only the valid region
+    const int eh = l1_sum ? h : h - k + 1, ew = l1_sum ? w : w - k + 1;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ssim_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; }
+    hipLaunchKernelGGL(ssim_fwd_kernel<0>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                       make_win(win_host, k), c1, c2, sums, l1_sum);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_avgpool2_planes(const float* in, float* out, int planes, int h, int w, pssr_stream_t s) {
+    PSSR_CHECK(in && out && planes > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "avgpool2_planes: bad args");
+    const int ho = (h + 2 * (h & 1) - 2) / 2 + 1, wo = (w + 2 * (w & 1) - 2) / 2 + 1;
+    const long total = (long)planes * ho * wo;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, in, out, planes, h, w, ho, wo);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_msssim_weights(const double* sums, int levels, int planes, const double* nvalid, const float* level_weights, int ms,
+                        float mix, const double* l1_sum, double l1_numel, const float* grad_out, float* loss_out, float* wts,
+                        float* l1_coef, pssr_stream_t s) {
+    PSSR_CHECK(sums && nvalid && loss_out && wts && l1_coef && levels > 0 && levels <= 8 && planes > 0, PSSR_ERR_ARG, "msssim_weights: bad args");
+    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, sums, levels, planes, nvalid, level_weights, ms, mix,
+                       l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1, float c2,
+                        const float* wts, int use_ssim, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx,
+                        pssr_stream_t s) {
+    PSSR_CHECK(x && y && wts && dx && win_host && planes > 0 && k > 0 && k <= MAXW && (k & 1), PSSR_ERR_ARG, "ssim_level_bwd: bad args");
+    const int halo = k - 1, AD = TS + halo, IN = TS + 2 * halo;
+    const size_t lds = (size_t)(2 * IN * IN + 5 * IN * AD + 3 * AD * AD) * sizeof(float);
+    PSSR_CHECK(lds <= 156 * 1024, PSSR_ERR_UNSUPPORTED, "ssim_level_bwd: window %d needs %zu bytes of LDS", k, lds);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ssim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; }
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                       make_win(win_host, k), c1, c2, wts, use_ssim, dcoarse, hc, wc, l1_coef, dx);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+}  // extern "C"

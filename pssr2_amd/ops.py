@@ -190,3 +190,39 @@ def clip_u8(x, out):
 
 def f64_to_f32(src, dst, accumulate=False):
     L.check(L.lib().pssr_f64_to_f32(L.ptr(src), L.ptr(dst), dst.numel(), int(accumulate), L.stream_ptr()), "pssr_f64_to_f32")
+
+
+# ----------------------------------------------------------------------------------------------
+# loss + optimizer (csrc/loss.hip, csrc/optim.hip)
+def _win(win):
+    arr = (C.c_float * len(win))(*[float(v) for v in win])
+    return arr, len(win)
+
+
+def ssim_level_fwd(x, y, planes, h, w, win, c1, c2, sums, l1_sum=None):
+    arr, k = _win(win)
+    L.check(L.lib().pssr_ssim_level_fwd(L.ptr(x), L.ptr(y), planes, h, w, arr, k, C.c_float(c1), C.c_float(c2), L.ptr(sums),
+                                        L.ptr(l1_sum), L.stream_ptr()), "pssr_ssim_level_fwd")
+
+
+def avgpool2_planes(x, out, planes, h, w):
+    L.check(L.lib().pssr_avgpool2_planes(L.ptr(x), L.ptr(out), planes, h, w, L.stream_ptr()), "pssr_avgpool2_planes")
+
+
+def msssim_weights(sums, levels, planes, nvalid, level_weights, ms, mix, l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef):
+    L.check(L.lib().pssr_msssim_weights(L.ptr(sums), levels, planes, L.ptr(nvalid), L.ptr(level_weights), int(ms), C.c_float(mix),
+                                        L.ptr(l1_sum), C.c_double(l1_numel), L.ptr(grad_out), L.ptr(loss_out), L.ptr(wts),
+                                        L.ptr(l1_coef), L.stream_ptr()), "pssr_msssim_weights")
+
+
+def ssim_level_bwd(x, y, planes, h, w, win, c1, c2, wts, use_ssim, dcoarse, hc, wc, l1_coef, dx):
+    arr, k = _win(win)
+    L.check(L.lib().pssr_ssim_level_bwd(L.ptr(x), L.ptr(y), planes, h, w, arr, k, C.c_float(c1), C.c_float(c2), L.ptr(wts),
+                                        int(use_ssim), L.ptr(dcoarse), hc, wc, L.ptr(l1_coef), L.ptr(dx), L.stream_ptr()),
+            "pssr_ssim_level_bwd")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    L.check(L.lib().pssr_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), C.c_float(lr), C.c_float(beta1),
+                                    C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_int64(step), C.c_float(grad_scale),
+                                    L.stream_ptr()), "pssr_adamw_step")

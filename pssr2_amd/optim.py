@@ -1,0 +1,66 @@
+"""FusedAdamW: ``torch.optim.AdamW`` semantics with the update done by one HIP kernel per flat
+buffer (csrc/optim.hip).  Parameters and gradients are flattened into one f32 buffer each so that
+the step is a single launch and the data-parallel all-reduce sees a few large messages."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = {}
+
+    def _flatten(self, gi, group):
+        """Move the group's parameters into one flat buffer (views keep shapes and identity)."""
+        params = [p for p in group["params"]]
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("FusedAdamW runs on an MI355X (HIP) device only")
+        offs, tot = [], 0
+        for p in params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        st = dict(flat=flat, grad=torch.zeros_like(flat), m=torch.zeros_like(flat), v=torch.zeros_like(flat), offs=offs, step=0,
+                  ptrs=[p.data_ptr() for p in params])
+        self._flat[gi] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            params = group["params"]
+            if st is None or any(p.data_ptr() != q for p, q in zip(params, st["ptrs"])):
+                old = st
+                st = self._flatten(gi, group)
+                if old is not None and old["flat"].numel() == st["flat"].numel():
+                    st["m"], st["v"], st["step"] = old["m"], old["v"], old["step"]
+            g = st["grad"]
+            for p, o in zip(params, st["offs"]):
+                if p.grad is None:
+                    g[o:o + p.numel()].zero_()
+                elif p.grad.data_ptr() != g.data_ptr() + 4 * o:
+                    g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
+                           grad_scale)
+        return loss
+
+    def flat_grad(self, gi=0):
+        """Flat gradient buffer of a group (the engine writes into it directly when it can)."""
+        st = self._flat.get(gi)
+        return None if st is None else st["grad"]

@@ -1,0 +1,161 @@
+"""Loss, metrics and small host helpers with the reference's names (pssr/util.py).
+
+``SSIMLoss`` keeps the reference signature and semantics (pssr/util.py:10-52) but runs as two HIP
+kernel sweeps over the image pyramid (csrc/loss.hip) instead of ~60 torch ops; the third-party
+pytorch_msssim algorithm it stands for is restated in oracle/loss_ref.py.
+"""
+from __future__ import annotations
+
+import inspect
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+MS_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)    # pytorch_msssim default level weights
+
+
+def _gauss_1d(size: int, sigma: float):
+    coords = torch.arange(size, dtype=torch.float) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return (g / g.sum()).tolist()
+
+
+class _SSIMLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, cfg):
+        if not x.is_cuda:
+            raise RuntimeError("pssr2_amd.SSIMLoss runs on an MI355X (HIP) device only; there is no CPU fallback")
+        win, mix, ms, k1, k2, data_range, lvl_w = cfg
+        x = x.detach().contiguous().float()
+        y = y.detach().contiguous().float()
+        n, c, h, w = x.shape
+        planes, k = n * c, len(win)
+        levels = len(lvl_w) if ms else 1
+        if ms and min(h, w) <= (k - 1) * 2 ** 4:
+            raise AssertionError(f"Image size should be larger than {(k - 1) * 2 ** 4} due to the 4 downsamplings in ms-ssim")
+        c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+        dev = x.device
+        xs, ys, dims = [x], [y], [(h, w)]
+        for _ in range(1, levels):
+            hh, ww = dims[-1]
+            ho, wo = (hh + 2 * (hh & 1) - 2) // 2 + 1, (ww + 2 * (ww & 1) - 2) // 2 + 1
+            xo = torch.empty(planes, ho, wo, device=dev)
+            yo = torch.empty(planes, ho, wo, device=dev)
+            ops.avgpool2_planes(xs[-1], xo, planes, hh, ww)
+            ops.avgpool2_planes(ys[-1], yo, planes, hh, ww)
+            xs.append(xo), ys.append(yo), dims.append((ho, wo))
+        sums = torch.zeros(levels * planes * 2 + 2, dtype=torch.float64, device=dev)
+        l1_sum = sums[-2:-1] if mix < 1 else None
+        for l in range(levels):
+            hh, ww = dims[l]
+            ops.ssim_level_fwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, sums[l * planes * 2:], l1_sum if l == 0 else None)
+        nvalid = torch.tensor([float((hh - k + 1) * (ww - k + 1)) for hh, ww in dims], dtype=torch.float64, device=dev)
+        lw = torch.tensor(list(lvl_w) if ms else [1.0], dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wts = torch.empty(levels * planes, dtype=torch.float32, device=dev)
+        l1c = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()), None, loss, wts, l1c)
+        ctx.saved = (xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, x.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, shape = ctx.saved
+        win, mix, ms, k1, k2, data_range, lvl_w = cfg
+        levels = len(xs)
+        dev = xs[0].device
+        c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+        go = grad_out.detach().float().reshape(1).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wts = torch.empty(levels * planes, dtype=torch.float32, device=dev)
+        l1c = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(xs[0].numel()), go, loss, wts, l1c)
+        dcoarse, hc, wc = None, 0, 0
+        for l in range(levels - 1, -1, -1):
+            hh, ww = dims[l]
+            dx = torch.empty(planes, hh, ww, device=dev)
+            use_ssim = (l == levels - 1)
+            ops.ssim_level_bwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, wts[l * planes:], use_ssim, dcoarse, hc, wc,
+                               l1c if (l == 0 and l1_sum is not None) else None, dx)
+            dcoarse, hc, wc = dx, hh, ww
+        return dcoarse.view(shape), None, None
+
+
+class SSIMLoss(nn.Module):
+    def __init__(self, channels: int = 1, mix: float = .8, win_size: int = 11, win_sigma: float = 1.5, ms: bool = True, kwargs=None):
+        r"""SSIM / MS-SSIM loss mixed with a Gaussian-weighted L1 term (Zhao et al., 2018), reference
+        signature (pssr/util.py:11).  ``kwargs`` accepts the pytorch_msssim options ``K`` and
+        ``weights``.  For ``channels > 1`` the L1 window is depthwise (the reference's [1,1,k,k]
+        window raises in torch for C > 1).
+        """
+        super().__init__()
+        kwargs = {} if kwargs is None else dict(kwargs)
+        if win_size % 2 != 1:
+            raise ValueError("Window size should be odd.")
+        self.K = tuple(kwargs.pop("K", (0.01, 0.03)))
+        self.weights = tuple(kwargs.pop("weights", None) or MS_WEIGHTS)
+        if kwargs:
+            raise TypeError(f"unsupported pytorch_msssim options on the MI355X path: {sorted(kwargs)}")
+        self.win = _gauss_1d(win_size, win_sigma)
+        self.channels, self.win_size, self.mix, self.ms = channels, win_size, mix, ms
+
+    def forward(self, input, target):
+        if input.shape != target.shape:
+            raise ValueError(f"Input images should have the same dimensions, but got {input.shape} and {target.shape}.")
+        cfg = (self.win, float(self.mix), bool(self.ms), self.K[0], self.K[1], 1.0, self.weights)
+        return _SSIMLossFunction.apply(input, target, cfg)
+
+
+def ssim(X, Y, data_range=255, win_size=11, win_sigma=1.5):
+    """Mean SSIM (the in-loop metric of pssr/train.py:109), forward only."""
+    cfg = (_gauss_1d(win_size, win_sigma), 1.0, False, 0.01, 0.03, float(data_range), (1.0,))
+    with torch.no_grad():
+        return 1 - _SSIMLossFunction.apply(X, Y, cfg)
+
+
+def pixel_metric(mse: float, image_range: int = 255):
+    r"""Average pixel error from a mean squared error (pssr/util.py:207-215)."""
+    return math.sqrt(mse) * image_range
+
+
+def _psnr_metric(mse):
+    return 20 * torch.log10(1 / torch.sqrt(mse))
+
+
+def _force_list(item):
+    if type(item) is not list:
+        try:
+            return list(item)
+        except TypeError:
+            return [item]
+    return item
+
+
+def _get_callbacks(raw):
+    """1-argument callbacks receive ``locals()`` of the driver loop (pssr/util.py:228-231)."""
+    callbacks = [] if raw is None else _force_list(raw)
+    takes_locals = [len([a for a in inspect.getfullargspec(cb).args if a != "self"]) == 1 for cb in callbacks]
+    return callbacks, takes_locals
+
+
+def _patch_images(batched, n_cols, n_rows, overlap, margin):
+    """Overlap-averaged stitching of row-major tiles (pssr/util.py:116-137), host numpy."""
+    size = batched.shape[-1]
+    step = size - overlap
+    H, W = n_rows * step + overlap, n_cols * step + overlap
+    acc, cnt = np.zeros((H, W)), np.zeros((H, W))
+    for idx in range(n_rows * n_cols):
+        row, col = divmod(idx, n_cols)
+        top = margin if row != 0 else 0
+        bot = margin if row != n_rows - 1 else 0
+        lef = margin if col != 0 else 0
+        rig = margin if col != n_cols - 1 else 0
+        r0, c0 = row * step, col * step
+        acc[r0 + top:r0 + size - bot, c0 + lef:c0 + size - rig] += batched[idx, top:batched.shape[1] - bot, lef:batched.shape[2] - rig]
+        cnt[r0 + top:r0 + size - bot, c0 + lef:c0 + size - rig] += 1
+    cnt[cnt == 0] = 1
+    return acc / cnt
