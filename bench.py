@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the PSSR2 hot path on MI355X: HR tiles/s of one ResUNet training step.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): ResUNet 1-ch 4xSR, 128^2 -> 512^2, bf16 storage / f32 accumulate,
+batch 32 per GPU, SSIMLoss(mix=.8) (MS-SSIM + L1), AdamW.  A step = device-side pair generation
+(Pillow-exact 4x reduction + AdditiveGaussian(13) + round/clip) from uint8 HR tiles already resident in
+HBM, forward, loss, backward, (gradient all-reduce), optimizer update.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GFLOP_PER_TILE = 189.91      # 31.652 GMAC fwd x 2 FLOP x 3 (fwd + dgrad + wgrad), c2
+FWD_GFLOP_PER_TILE = 63.30
+PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+class ConvTimer:
+    """HIP-event timing of the dominant kernel (conv_igemm<bf16,128,geo0>) on the launch stream."""
+
+    def __init__(self):
+        self.events = []
+        self.orig = None
+
+    def install(self):
+        from pssr2_amd import ops
+        self.orig = ops.conv2d
+        timer = self
+
+        def timed(x, cin0, w0, out, cout, **kw):
+            w = kw["w"]
+            dominant = cout > 64 and w > 8 and w0.dtype == 1
+            if not dominant:
+                return timer.orig(x, cin0, w0, out, cout, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer.orig(x, cin0, w0, out, cout, **kw)
+            e1.record()
+            flops = 2.0 * kw["n"] * kw["h"] * w * cout * (w0.taps * min(cin0, w0.k_pad) + kw.get("cin1", 0))
+            timer.events.append((e0, e1, flops))
+            return r
+        ops.conv2d = timed
+        import pssr2_amd.engine as E
+        E.ops.conv2d = timed
+
+    def remove(self):
+        from pssr2_amd import ops
+        ops.conv2d = self.orig
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self.events]
+        fl = [f for _, _, f in self.events]
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        return dict(launches=len(ms), avg_us=1e3 * tot_ms / len(ms), tflops=tot_fl / (tot_ms * 1e-3) / 1e12,
+                    gflop_per_launch=tot_fl / len(ms) / 1e9)
+
+
+def cpu_baseline(batch=2, lr_res=128):
+    """The oracle (CPU restatement, torch fp32) doing the same training step on a bounded sample."""
+    from oracle import loss_ref, model_ref
+    torch.manual_seed(0)
+    sd = model_ref.make_state_dict(seed=1, randomize_bn=False)
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-3)
+    lr = torch.rand(batch, 1, lr_res, lr_res) * 255
+    hr = torch.rand(batch, 1, lr_res * 4, lr_res * 4) * 255
+    t0 = time.time()
+    y, _ = model_ref.resunet_forward(lr, params, 5, 3, 4, train=True)
+    loss = loss_ref.ssim_loss(y / 255, hr / 255, mix=0.8)
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return dict(value=batch / dt, unit="HR tiles/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 training step (fwd + MS-SSIM/L1 + bwd + AdamW) of the CPU oracle on {batch} tiles {lr_res}^2->{lr_res * 4}^2, fp32, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
+    ap.add_argument("--lr-res", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pssr2_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local if world > 1 else 0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DevicePairGenerator, synthetic_em_tile
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.util import SSIMLoss
+    import numpy as np
+
+    torch.manual_seed(0)
+    model = ResUNet().to(dev)
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    D.broadcast_module(model)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    loss_fn = SSIMLoss(mix=0.8)
+    hr_res = args.lr_res * 4
+    pool_n = 8                                           # distinct synthetic EM tiles per rank (tiled to the batch)
+    pool = np.stack([synthetic_em_tile(rank * 100003 + i, hr_res) for i in range(pool_n)])
+    pool = torch.from_numpy(pool).to(dev)                # uint8 [pool, 1, HR, HR], resident in HBM
+    gen = DevicePairGenerator(4, AdditiveGaussian(13, 0, 0), seed=1234)
+    if world > 1:
+        model._engine.attach_reducer()
+    state = {"tile": rank * 10 ** 9}
+
+    def batch_u8(step):
+        idx = (torch.arange(args.batch, device=dev) + step) % pool_n
+        return pool[idx]
+
+    def train_step(step):
+        hr, lr = gen(batch_u8(step), tile_offset=state["tile"])
+        state["tile"] += args.batch
+        hr_hat = model(lr)
+        loss = loss_fn(hr_hat / 255, hr / 255)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    def infer_step(step):
+        _, lr = gen(batch_u8(step), tile_offset=state["tile"])
+        with torch.no_grad():
+            y = model(lr)
+            out = torch.empty(y.shape, dtype=torch.uint8, device=dev)
+            from pssr2_amd import ops
+            ops.clip_u8(y, out)
+        return out
+
+    if args.mode == "train":
+        model.train()
+        fn = train_step
+    else:
+        model.eval()
+        fn = infer_step
+
+    for s in range(args.warmup):
+        fn(s)
+    timer = ConvTimer()
+    if rank == 0 and args.dtype == "bf16":
+        timer.install()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        fn(args.warmup + s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        conv = timer.summary()
+        tiles_per_s = world * args.batch * args.steps / elapsed
+        gflop_tile = TRAIN_GFLOP_PER_TILE if args.mode == "train" else FWD_GFLOP_PER_TILE
+        scale = (args.lr_res / 128) ** 2
+        res = {
+            "metric": f"HR tiles/sec (512^2 4xSR) {args.mode}",
+            "value": round(tiles_per_s, 2), "unit": "HR tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ResUNet 1-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
+                                   f"AdditiveGaussian(13) device crappifier, MS-SSIM+L1 (mix .8), AdamW",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "step_compute": {"algorithmic_tflops": round(tiles_per_s * gflop_tile * scale / 1e3 / world, 2),
+                             "frac_of_bf16_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / PEAK_BF16_TFLOPS, 4)},
+        }
+        if conv:
+            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile> (3x3/1x1 conv fwd+dgrad)",
+                               "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1),
+                               "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2)}
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -225,6 +225,30 @@ int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                     pssr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pair generation / crappifiers (pssr/data.py:471-495, pssr/crappifiers.py).
+ */
+/* PIL.Image.resize(BILINEAR) of uint8 planes [planes][H][W] -> [planes][h][w], bit-exact with Pillow's
+ * two-pass 22-bit fixed-point resampler (pssr/data.py:483).  `tmp` holds [planes][H][w] bytes. */
+int pssr_bilinear_down_u8(const uint8_t* hr, uint8_t* tmp, uint8_t* lr, int planes, int H, int W,
+                          int h, int w, pssr_stream_t stream);
+int pssr_u8_to_f32(const uint8_t* in, float* out, int64_t n, pssr_stream_t stream);
+/* flags: 1 = clip to [0,255] (MultiCrappifier, crappifiers.py:41-42); 2 = np.round (half-to-even) then
+ * clip (data.py:487).  Noise comes from Philox4x32-10 keyed by (seed, tile_offset + tile) with the pixel
+ * index as counter, so results do not depend on batching or on the number of GPUs.
+ * AdditiveGaussian (crappifiers.py:62-64): out = in + N(gain, sigma), sigma = max(N(intensity, spread), 0)
+ * per tile; `noise` (f64, may be NULL) injects a pre-drawn field instead (exact-parity tests). */
+int pssr_crappify_gaussian(const float* in, float* out, int tiles, int64_t per_tile, float intensity,
+                           float gain, float spread, uint64_t seed, uint64_t tile_offset,
+                           const double* noise, int flags, pssr_stream_t stream);
+/* Poisson (crappifiers.py:81-86): out = x*(1-i) + Poisson(max(x,0))*i + gain */
+int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_tile, float intensity,
+                          float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags,
+                          pssr_stream_t stream);
+/* Blur (crappifiers.py:122-124): per-plane separable Gaussian, edge replicate, radius int(4*sigma+.5) */
+int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int h, int w, float sigma,
+                       float gain, int flags, pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

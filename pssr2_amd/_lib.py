@@ -59,6 +59,7 @@ def lib():
             raise RuntimeError(
                 f"{_LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
                 "or make -C pssr2_amd/csrc). pssr2_amd has no CPU fallback.")
+        import torch  # noqa: F401  (load torch's HIP runtime first: one libamdhip64 per process)
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.pssr_last_error.restype = C.c_char_p
         _lib.pssr_packed_weight_bytes.restype = C.c_int64

@@ -1,0 +1,245 @@
+// Crappifier / pair-generation kernels (pssr/data.py:471-495, pssr/crappifiers.py): integer-exact
+// Pillow BILINEAR reduction of uint8 tiles, additive-Gaussian / Poisson noise from a counter-based
+// Philox4x32-10 stream keyed by (seed, tile), Gaussian blur, and the round-half-even + clip that ends
+// _gen_pair.  All HBM-bound byte/float work: one thread per output element, coalesced rows.
+#include "common.h"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;   // Pillow ImagingResample 8bpc fixed point
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for one output index (bilinear = triangle filter).
+// Evaluated in double in Pillow's operation order, so the integer taps are the ones Pillow uses.
+struct Taps { int xmin, n; int k[40]; };
+__device__ __forceinline__ void pil_taps(int xx, int in_size, int out_size, Taps& t) {
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const double center = (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    const int n = xmax - xmin;
+    double w[40];
+    double ww = 0.0;
+    for (int x = 0; x < n && x < 40; ++x) {
+        double a = (x + xmin - center + 0.5) * ss;
+        if (a < 0.0) a = -a;
+        const double v = a < 1.0 ? 1.0 - a : 0.0;
+        w[x] = v; ww += v;
+    }
+    t.xmin = xmin; t.n = n < 40 ? n : 40;
+    for (int x = 0; x < t.n; ++x) {
+        const double v = ww != 0.0 ? w[x] / ww : w[x];
+        t.k[x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS)) : (int)(0.5 + v * (1 << PRECISION_BITS));
+    }
+}
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass: [planes][H][W] -> [planes][H][w]
+__global__ void resample_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int planes, int H, int W, int w) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= w) return;
+    Taps t; pil_taps(ox, W, w, t);
+    for (long row = blockIdx.y; row < (long)planes * H; row += gridDim.y) {
+        const uint8_t* src = in + row * W + t.xmin;
+        int acc = 1 << (PRECISION_BITS - 1);
+        for (int x = 0; x < t.n; ++x) acc += (int)src[x] * t.k[x];
+        out[row * w + ox] = clip8(acc);
+    }
+}
+// vertical pass: [planes][H][w] -> [planes][h][w]
+__global__ void resample_v_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int planes, int H, int h, int w) {
+    const int oy = blockIdx.y;
+    Taps t; pil_taps(oy, H, h, t);
+    for (int pl = blockIdx.z; pl < planes; pl += gridDim.z)
+        for (int ox = blockIdx.x * blockDim.x + threadIdx.x; ox < w; ox += gridDim.x * blockDim.x) {
+            const uint8_t* src = in + ((long)pl * H + t.xmin) * w + ox;
+            int acc = 1 << (PRECISION_BITS - 1);
+            for (int y = 0; y < t.n; ++y) acc += (int)src[(long)y * w] * t.k[y];
+            out[((long)pl * h + oy) * w + ox] = clip8(acc);
+        }
+}
+
+__global__ void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct Philox {
+    uint32_t key[2];
+    __device__ __forceinline__ Philox(uint64_t seed, uint64_t stream) {
+        // the stream (tile index) is folded into the key so that results do not depend on how tiles are batched
+        const uint64_t k = seed ^ (stream * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull);
+        key[0] = (uint32_t)k; key[1] = (uint32_t)(k >> 32);
+    }
+    __device__ __forceinline__ uint4 operator()(uint64_t counter, uint32_t sub) const {
+        uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = sub, c3 = 0x1BD11BDAu;
+        uint32_t k0 = key[0], k1 = key[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1) with 53 bits
+    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double normal_from(const uint4& r) {
+    const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+}
+__device__ __forceinline__ double finish(double v, int flags) {
+    if (flags & 2) v = rint(v);                 // np.round: round-half-to-even (pssr/data.py:487)
+    if (flags & 3) v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    return v;
+}
+// per-tile intensity: max(N(intensity, spread), 0) if spread > 0 else intensity
+__device__ __forceinline__ double tile_intensity(const Philox& ph, float intensity, float spread) {
+    if (!(spread > 0.f)) return intensity;
+    const double v = (double)intensity + (double)spread * normal_from(ph(~0ull, 7u));
+    return v > 0.0 ? v : 0.0;
+}
+
+__global__ void gaussian_noise_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, long per_tile, float intensity,
+                                      float gain, float spread, uint64_t seed, uint64_t tile_offset, const double* __restrict__ noise, int flags) {
+    const long total = (long)tiles * per_tile;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tile = i / per_tile, pix = i % per_tile;
+        double nz;
+        if (noise) nz = noise[i];
+        else {
+            const Philox ph(seed, tile_offset + tile);
+            nz = (double)gain + tile_intensity(ph, intensity, spread) * normal_from(ph((uint64_t)pix, 0u));
+        }
+        out[i] = (float)finish((double)in[i] + nz, flags);
+    }
+}
+
+// Poisson(lambda): Knuth product for lambda < 10, Hoermann's PTRS transformed rejection otherwise.
+__device__ double poisson_draw(const Philox& ph, uint64_t pix, double lam) {
+    if (lam <= 0.0) return 0.0;
+    uint32_t sub = 1;
+    if (lam < 10.0) {
+        const double enlam = exp(-lam);
+        double prod = 1.0; long x = 0;
+        for (int it = 0; it < 64; ++it) {
+            const uint4 r = ph(pix, sub++);
+            const double u[2] = {u01(r.x, r.y), u01(r.z, r.w)};
+            for (int j = 0; j < 2; ++j) { prod *= u[j]; if (prod > enlam) ++x; else return (double)x; }
+        }
+        return (double)x;
+    }
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 256; ++it) {
+        const uint4 r = ph(pix, sub++);
+        const double U = u01(r.x, r.y) - 0.5, V = u01(r.z, r.w);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam + 0.5);
+}
+
+__global__ void poisson_noise_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, long per_tile, float intensity,
+                                     float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags) {
+    const long total = (long)tiles * per_tile;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tile = i / per_tile, pix = i % per_tile;
+        const Philox ph(seed, tile_offset + tile);
+        const double x = (double)in[i];
+        const double y = poisson_draw(ph, (uint64_t)pix, x > 0.0 ? x : 0.0);
+        const double mixv = tile_intensity(ph, intensity, spread);
+        out[i] = (float)finish(x * (1.0 - mixv) + y * mixv + (double)gain, flags);
+    }
+}
+
+// separable Gaussian, edge replicate, truncate 4 sigma; f64 accumulate, f32 between the passes (scipy.ndimage)
+__global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, float sigma, int axis,
+                                 float gain, int flags) {
+    const int r = (int)(4.0f * sigma + 0.5f);
+    const long total = (long)planes * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = i % w, y = (i / w) % h;
+        const long base = i - (long)y * w - x;
+        double wsum = 0.0, acc = 0.0;
+        for (int t = -r; t <= r; ++t) {
+            const double wt = exp(-0.5 / ((double)sigma * sigma) * (double)t * t);
+            int yy = y, xx = x;
+            if (axis == 0) { yy = y + t; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy); }
+            else { xx = x + t; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx); }
+            wsum += wt; acc += wt * (double)in[base + (long)yy * w + xx];
+        }
+        double v = (double)(float)(acc / wsum);
+        if (axis == 1) v = finish((double)(float)v + (double)gain, flags);
+        out[i] = (float)v;
+    }
+}
+
+static inline int grid1d(long total) { long b = (total + 255) / 256; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
+
+}  // namespace
+
+extern "C" {
+
+int pssr_bilinear_down_u8(const uint8_t* hr, uint8_t* tmp, uint8_t* lr, int planes, int H, int W, int h, int w, pssr_stream_t s) {
+    PSSR_CHECK(hr && tmp && lr && planes > 0 && H > 0 && W > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "bilinear_down_u8: bad args");
+    PSSR_CHECK(H >= h && W >= w && (double)W / w <= 19.0 && (double)H / h <= 19.0, PSSR_ERR_UNSUPPORTED, "bilinear_down_u8: reduction ratio must be in [1, 19]");
+    long rows = (long)planes * H;
+    hipLaunchKernelGGL(resample_h_kernel, dim3(cdiv(w, 64), (unsigned)(rows < 65535 ? rows : 65535)), dim3(64), 0, (hipStream_t)s, hr, tmp, planes, H, W, w);
+    PSSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(resample_v_kernel, dim3(cdiv(w, 128), h, planes < 1024 ? planes : 1024), dim3(128), 0, (hipStream_t)s, tmp, lr, planes, H, h, w);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_u8_to_f32(const uint8_t* in, float* out, int64_t n, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0, PSSR_ERR_ARG, "u8_to_f32: bad args");
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)s, in, out, (long)n);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_crappify_gaussian(const float* in, float* out, int tiles, int64_t per_tile, float intensity, float gain, float spread,
+                           uint64_t seed, uint64_t tile_offset, const double* noise, int flags, pssr_stream_t s) {
+    PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_gaussian: bad args");
+    hipLaunchKernelGGL(gaussian_noise_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
+                       intensity, gain, spread, seed, tile_offset, noise, flags);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_tile, float intensity, float gain, float spread,
+                          uint64_t seed, uint64_t tile_offset, int flags, pssr_stream_t s) {
+    PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_poisson: bad args");
+    hipLaunchKernelGGL(poisson_noise_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
+                       intensity, gain, spread, seed, tile_offset, flags);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int h, int w, float sigma, float gain, int flags, pssr_stream_t s) {
+    PSSR_CHECK(in && tmp && out && planes > 0 && h > 0 && w > 0 && sigma > 0.f && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "gaussian_blur: bad args");
+    const long total = (long)planes * h * w;
+    hipLaunchKernelGGL(blur_pass_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, in, tmp, planes, h, w, sigma, 0, 0.f, 0);
+    PSSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blur_pass_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, tmp, out, planes, h, w, sigma, 1, gain, flags);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+}  // extern "C"

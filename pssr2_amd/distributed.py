@@ -1,0 +1,101 @@
+"""Data-parallel support: one process per GPU, gradients all-reduced by RCCL over xGMI.
+
+The reference has no multi-GPU code; tiles are independent, so the only exchange is one
+mean all-reduce of the gradients per step.  The engine keeps every gradient in ONE flat f32 buffer
+(parameter order); ``GradReducer`` cuts it into large buckets and launches an asynchronous all-reduce
+for a bucket as soon as the backward pass has finished every parameter inside it, so communication
+overlaps the remaining dgrad/wgrad kernels.  BatchNorm statistics stay per rank (DDP default).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world():
+    return (dist.get_rank(), dist.get_world_size()) if is_distributed() else (0, 1)
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_module(module, src=0):
+    """Rank-0 weights and BatchNorm buffers to every rank (what DDP does at construction)."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+class GradReducer:
+    """Bucketed asynchronous mean all-reduce over a flat gradient buffer."""
+
+    def __init__(self, flat, offsets, sizes, bucket_bytes=64 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # buckets = contiguous parameter ranges of ~bucket_bytes
+        self.buckets, cur, start = [], 0, 0
+        for i, (o, n) in enumerate(zip(offsets, sizes)):
+            cur += 4 * n
+            if cur >= bucket_bytes or i == len(sizes) - 1:
+                end = o + (n + 3) // 4 * 4
+                self.buckets.append([offsets[start], min(end, flat.numel()), start, i + 1])
+                start, cur = i + 1, 0
+        self.bucket_of = {}
+        for b, (_, _, s, e) in enumerate(self.buckets):
+            for i in range(s, e):
+                self.bucket_of[i] = b
+        self.begin()
+
+    def begin(self):
+        self.pending = [e - s for (_, _, s, e) in self.buckets]
+        self.handles = []
+
+    def mark_ready(self, param_indices):
+        for i in param_indices:
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0 and self.world > 1:
+                lo, hi = self.buckets[b][:2]
+                self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        self.handles = []
+
+
+def allreduce_mean_(tensors, group=None):
+    """Fallback used for models that are not on the engine: flatten, all-reduce, scatter back."""
+    if not is_distributed():
+        return
+    world = dist.get_world_size(group)
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, group=group)
+    flat.mul_(1.0 / world)
+    o = 0
+    for t in tensors:
+        t.copy_(flat[o:o + t.numel()].view_as(t))
+        o += t.numel()

@@ -93,6 +93,50 @@ class Engine:
         self.plans = {}
         self.saved = None
         self._convs = {}
+        self.reducer = None          # pssr2_amd.distributed.GradReducer when data-parallel
+        self._flat_grad = None
+
+    # ------------------------------------------------------------------ flat gradient buffer
+    def _grad_layout(self, device):
+        """All gradients live in one flat f32 buffer in parameter order (4-element aligned slots)."""
+        params = list(self.model.parameters())
+        key = (str(device), tuple(p.numel() for p in params))
+        if self._flat_grad is not None and self._flat_key == key:
+            return
+        offs, tot = [], 0
+        for p in params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        self._flat_grad = torch.zeros(tot, dtype=torch.float32, device=device)
+        self._flat_key = key
+        self._goffs = offs
+        self._gsizes = [p.numel() for p in params]
+        self._gindex = {id(p): i for i, p in enumerate(params)}
+        self._gviews = [self._flat_grad[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+
+    def attach_reducer(self, bucket_bytes=64 << 20, group=None):
+        from .distributed import GradReducer
+        dev = next(self.model.parameters()).device
+        self._grad_layout(dev)
+        self.reducer = GradReducer(self._flat_grad, self._goffs, self._gsizes, bucket_bytes, group)
+        return self.reducer
+
+    def _gbuf(self, param):
+        """Zeroed gradient slot of a parameter (a view of the flat buffer)."""
+        return self._gviews[self._gindex[id(param)]]
+
+    def _ready(self, grads, params):
+        """Copy small side results into their slots and tell the reducer these parameters are final."""
+        idx = []
+        for prm in params:
+            i = self._gindex[id(prm)]
+            g = grads.get(id(prm))
+            if g is not None and g.data_ptr() != self._gviews[i].data_ptr():
+                self._gviews[i].copy_(g.view(prm.shape))
+            grads[id(prm)] = self._gviews[i]
+            idx.append(i)
+        if self.reducer is not None:
+            self.reducer.mark_ready(idx)
 
     # ------------------------------------------------------------------ static structure
     def _structure(self, device):
@@ -323,7 +367,7 @@ class Engine:
             grads[gname] = g3[:, :, 1:2, 1:2].contiguous()
             return
         if gname not in grads:
-            grads[gname] = torch.zeros_like(w, dtype=torch.float32)
+            grads[gname] = self._gbuf(w)          # zeroed at the start of backward
         ops.unpack_conv_wgrad(dwp, grads[gname], mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
 
     def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
@@ -347,7 +391,7 @@ class Engine:
         for k in range(nl - 1, 0, -1):
             conv = module.conv[3 * k]
             prev, bn_prev = blk.bn[k - 1], module.conv[3 * (k - 1) + 1]
-            grads[id(conv.bias)] = torch.zeros_like(conv.bias)     # bias in front of a batch-stat BN: exactly zero
+            # conv.bias sits in front of a batch-statistics BN: its gradient is exactly zero (slot stays zeroed)
             self._wgrad(p, grads, conv, dy, blk.c, blk.y[k - 1], blk.c, 9, pro=prev, hh=hh, ww=ww)
             pwd = self._conv(conv, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
             ops.conv2d(dy, blk.c, pwd, g, blk.c, n=n, h=hh, w=ww, epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS,
@@ -358,7 +402,6 @@ class Engine:
             grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
             ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy, npix, blk.c, code)
         conv0, rp = module.conv[0], module.respass
-        grads[id(conv0.bias)] = torch.zeros_like(conv0.bias)
         if first:
             self._wgrad(p, grads, conv0, dy, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww)
             self._wgrad(p, grads, rp, dz, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww, center=True)
@@ -370,6 +413,7 @@ class Engine:
             c0 = self._conv(conv0, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
             c1 = self._conv(rp, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
         ops.conv2d(dy, blk.c, c0, dsrc, dsrc_c, n=n, h=hh, w=ww, x1=dz, cin1=blk.c, w1=c1)
+        self._ready(grads, list(module.parameters()))
 
     def backward(self, dout):
         if self.saved is None:
@@ -383,6 +427,15 @@ class Engine:
         Lv, hid, r = self.L, self.hidden, self.r
         h0 = hid[0]
         grads = {}
+        self._grad_layout(dev)
+        for prm, view in zip(m.parameters(), self._gviews):
+            # a .grad still aliasing our buffer (zero_grad(set_to_none=False) or deliberate accumulation):
+            # detach it first so that autograd's accumulation stays correct
+            if prm.grad is not None and prm.grad.data_ptr() == view.data_ptr():
+                prm.grad = prm.grad.clone()
+        self._flat_grad.zero_()
+        if self.reducer is not None:
+            self.reducer.begin()
         rec = m.reconstruction
         H, W = h * r, w * r
         dout = dout.contiguous().float()
@@ -412,6 +465,7 @@ class Engine:
         self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
         self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
                     n_perm=self.pre_perm, hh=h, ww=w)
+        self._ready(grads, list(rec.parameters()))
         cpre = self._convs[id(rec.pre)]
         dfeat = bw.dout[0]
         ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
@@ -446,4 +500,7 @@ class Engine:
         dgam, dbet = torch.empty_like(m.norm.weight), torch.empty_like(m.norm.bias)
         ops.bn_bwd_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
+        self._ready(grads, list(m.norm.parameters()))
+        if self.reducer is not None:
+            self.reducer.finish()
         return grads

@@ -226,3 +226,52 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     L.check(L.lib().pssr_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), C.c_float(lr), C.c_float(beta1),
                                     C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_int64(step), C.c_float(grad_scale),
                                     L.stream_ptr()), "pssr_adamw_step")
+
+
+# ----------------------------------------------------------------------------------------------
+# pair generation / crappifiers (csrc/crappify.hip)
+ROUND_CLIP, CLIP = 2, 1
+
+
+def bilinear_down_u8(hr, h, w):
+    """uint8 [..., H, W] -> uint8 [..., h, w] (Pillow BILINEAR, bit-exact)."""
+    assert hr.dtype == torch.uint8 and hr.is_cuda and hr.is_contiguous()
+    H, W = hr.shape[-2:]
+    planes = hr.numel() // (H * W)
+    tmp = torch.empty(planes * H * w, dtype=torch.uint8, device=hr.device)
+    lr = torch.empty(*hr.shape[:-2], h, w, dtype=torch.uint8, device=hr.device)
+    L.check(L.lib().pssr_bilinear_down_u8(L.ptr(hr), L.ptr(tmp), L.ptr(lr), planes, H, W, h, w, L.stream_ptr()), "pssr_bilinear_down_u8")
+    return lr
+
+
+def u8_to_f32(x):
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().pssr_u8_to_f32(L.ptr(x), L.ptr(out), C.c_int64(x.numel()), L.stream_ptr()), "pssr_u8_to_f32")
+    return out
+
+
+def crappify_gaussian(x, intensity, gain, spread, seed, tile_offset, flags, noise=None, out=None):
+    out = torch.empty_like(x) if out is None else out
+    tiles = x.shape[0]
+    L.check(L.lib().pssr_crappify_gaussian(L.ptr(x), L.ptr(out), tiles, C.c_int64(x.numel() // tiles), C.c_float(intensity), C.c_float(gain),
+                                           C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), L.ptr(noise), flags,
+                                           L.stream_ptr()), "pssr_crappify_gaussian")
+    return out
+
+
+def crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, out=None):
+    out = torch.empty_like(x) if out is None else out
+    tiles = x.shape[0]
+    L.check(L.lib().pssr_crappify_poisson(L.ptr(x), L.ptr(out), tiles, C.c_int64(x.numel() // tiles), C.c_float(intensity), C.c_float(gain),
+                                          C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), flags, L.stream_ptr()),
+            "pssr_crappify_poisson")
+    return out
+
+
+def gaussian_blur(x, sigma, gain, flags):
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    L.check(L.lib().pssr_gaussian_blur(L.ptr(x), L.ptr(tmp), L.ptr(out), planes, h, w, C.c_float(sigma), C.c_float(gain), flags,
+                                       L.stream_ptr()), "pssr_gaussian_blur")
+    return out

@@ -49,11 +49,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 if old is not None and old["flat"].numel() == st["flat"].numel():
                     st["m"], st["v"], st["step"] = old["m"], old["v"], old["step"]
             g = st["grad"]
-            for p, o in zip(params, st["offs"]):
-                if p.grad is None:
-                    g[o:o + p.numel()].zero_()
-                elif p.grad.data_ptr() != g.data_ptr() + 4 * o:
-                    g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            base = getattr(params[0].grad, "_base", None) if params[0].grad is not None else None
+            if (base is not None and base.dtype == torch.float32 and base.numel() == g.numel() and
+                    all(p.grad is not None and p.grad._base is base and p.grad.data_ptr() == base.data_ptr() + 4 * o
+                        for p, o in zip(params, st["offs"]))):
+                g = base                  # the engine's flat gradient buffer has exactly our layout: no copy
+            else:
+                for p, o in zip(params, st["offs"]):
+                    if p.grad is None:
+                        g[o:o + p.numel()].zero_()
+                    elif p.grad.data_ptr() != g.data_ptr() + 4 * o:
+                        g[o:o + p.numel()].copy_(p.grad.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
             ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],

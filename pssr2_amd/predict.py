@@ -1,0 +1,79 @@
+"""``predict_images`` with the reference's signature (pssr/predict.py:11-83): batched no-grad forward,
+clip + uint8 truncation on the device (csrc/elementwise.hip: pssr_clip_u8), crop, dict or file output."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader, Dataset
+
+from . import distributed as D
+from . import ops
+from .data import _slice_center
+from .util import _get_callbacks
+
+try:
+    from tqdm import tqdm
+except ImportError:                                   # pragma: no cover
+    def tqdm(it, **kw):
+        return it
+
+
+def _pred_array(data: torch.Tensor, n_frames: int = 1):
+    """``np.clip(x, 0, 255).astype(np.uint8)`` (truncation) + centre-frame slice (pssr/predict.py:245-246)."""
+    if not data.is_cuda:
+        raise RuntimeError("pssr2_amd.predict runs on an MI355X (HIP) device only; there is no CPU fallback")
+    x = data.detach().contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    ops.clip_u8(x, out)
+    return _slice_center(out.cpu().numpy(), n_frames)
+
+
+def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batch_size=None, out_dir: str = "preds", norm: bool = False,
+                   prefix: str = None, dataloader_kwargs=None, callbacks=None):
+    r"""Predicts high-resolution images for ``dataset.val_idx``; returns ``{name: uint8 [C,H,W]}`` when
+    ``out_dir`` is None, else writes ``{out_dir}/{prefix_}{name}.tif`` through Pillow."""
+    dataloader_kwargs = {} if dataloader_kwargs is None else dataloader_kwargs
+    batch_size = 1 if batch_size is None else batch_size
+    if norm and dataset.is_lr:
+        raise ValueError("Dataset must be paired with high-low-resolution images for normalization.")
+    if norm:
+        raise NotImplementedError("normalize_preds (SURVEY.md §8f-3) is not part of the MI355X hot path yet")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    callbacks, callback_locals = _get_callbacks(callbacks)
+    rank, world = D.rank_world()
+
+    model.to(device)
+    model.eval()
+    idx = list(dataset.val_idx)
+    if world > 1:                                     # contiguous chunk per rank keeps output naming intact
+        per = (len(idx) + world - 1) // world
+        first = rank * per
+        idx = idx[first:first + per]
+    else:
+        first = 0
+    dataloader = DataLoader(dataset, batch_size, sampler=idx, **dataloader_kwargs)
+    outs, cur_idx = {}, first
+    with torch.no_grad():
+        for item in tqdm(dataloader, disable=rank != 0):
+            lr = item if dataset.is_lr else item[1]
+            lr = lr.to(device)
+            hr_hat = _pred_array(model(lr))
+            crop_res = dataset.crop_res if not dataset.is_lr else dataset.crop_res * (hr_hat.shape[-1] // lr.shape[-1])
+            hr_hat = hr_hat[:, :, :crop_res, :crop_res]
+            for batch_idx, image_idx in enumerate(range(cur_idx, min(cur_idx + batch_size, first + len(idx)))):
+                name = dataset._get_name(image_idx)
+                if out_dir:
+                    from PIL import Image
+                    frames = [Image.fromarray(f) for f in hr_hat[batch_idx]]
+                    frames[0].save(f"{out_dir}/{prefix + '_' if prefix else ''}{name}.tif", save_all=len(frames) > 1, append_images=frames[1:])
+                else:
+                    outs[name] = hr_hat[batch_idx]
+                for i, callback in enumerate(callbacks):
+                    callback(locals()) if callback_locals[i] else callback()
+            cur_idx += batch_size
+    if out_dir is None:
+        return outs
