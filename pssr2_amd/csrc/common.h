@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging register (native vector: stays in VGPRs)
 
 // A "slot" is 16 bytes of consecutive channels of one pixel: 8 bf16 or 4 f32.  Every tile in
 // LDS is made of 32-byte rows (2 slots) so that the bf16 and f32 builds share one byte geometry.
@@ -18,46 +19,45 @@ template <> struct TT<float> {
     static constexpr int EPS = 4;      // elements per slot
     static constexpr int KCH = 8;      // channels per K-chunk (2 slots)
     typedef f32x4 frag_t;
-    static __device__ __forceinline__ void unpack(const uint4& raw, float* f) {
-        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
-        f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+    static __device__ __forceinline__ void unpack(const u32x4& raw, float* f) {
+        f[0] = __uint_as_float(raw[0]); f[1] = __uint_as_float(raw[1]);
+        f[2] = __uint_as_float(raw[2]); f[3] = __uint_as_float(raw[3]);
     }
-    static __device__ __forceinline__ uint4 pack(const float* f) {
-        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    static __device__ __forceinline__ u32x4 pack(const float* f) {
+        u32x4 r = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+        return r;
     }
     static __device__ __forceinline__ float round(float v) { return v; }
     // 32x32 tile, K = one slot per lane half: 4 x v_mfma_f32_32x32x2_f32 (exact f32 fma chain)
-    static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[0]), __uint_as_float(b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[1]), __uint_as_float(b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[2]), __uint_as_float(b[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[3]), __uint_as_float(b[3]), c, 0, 0, 0);
     }
 };
 template <> struct TT<bf16_t> {
     static constexpr int EPS = 8;
     static constexpr int KCH = 16;
     typedef bf16x8 frag_t;
-    static __device__ __forceinline__ void unpack(const uint4& raw, float* f) {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    static __device__ __forceinline__ void unpack(const u32x4& raw, float* f) {
+        const uint32_t w[4] = {raw[0], raw[1], raw[2], raw[3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f[2 * i] = __uint_as_float(w[i] << 16);
             f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    static __device__ __forceinline__ uint4 pack(const float* f) {
-        union { bf16x8 v; uint4 u; } cv;
+    static __device__ __forceinline__ u32x4 pack(const float* f) {
+        bf16x8 v;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cv.v[i] = (bf16_t)f[i];
-        return cv.u;
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+        return __builtin_bit_cast(u32x4, v);
     }
     static __device__ __forceinline__ float round(float v) { return (float)(bf16_t)v; }
     // one v_mfma_f32_32x32x16_bf16
-    static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
-        union { uint4 u; bf16x8 v; } ca, cb;
-        ca.u = a; cb.u = b;
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca.v, cb.v, c, 0, 0, 0);
+    static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 

@@ -12,6 +12,8 @@
 // while chunk i is multiplied.  The accumulators leave through LDS so that every epilogue
 // (bias, ReLU, residual tail, ReLU mask, f64 BatchNorm statistics) runs on pixel-major rows and
 // the stores are coalesced along channels.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -54,7 +56,7 @@ template <int BN, int GEO> struct Cfg {
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
 };
 
-template <typename T, int BN, int GEO>
+template <typename T, int BN, int GEO, int TAPS0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     using C = Cfg<BN, GEO>;
     using X = TT<T>;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
 
     // ---- per-thread staging descriptors for the input halo (same pixels for every chunk)
-    long a_pix[C::A_ITEMS];   // source 0 (possibly blocked order); source 1 is always plain NHWC
+    long a_pix[C::A_ITEMS], a_pix1[C::A_ITEMS];   // source 0 (possibly blocked order); source 1 is always plain NHWC
     int a_lds[C::A_ITEMS];
     bool a_ok[C::A_ITEMS];
     int a_half[C::A_ITEMS];
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         const bool inb = (idx < 2 * C::HP) && gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         a_ok[it] = inb;
         a_pix[it] = inb ? pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) : 0;
+        a_pix1[it] = inb ? ((long)gi * p.H + gy) * p.W + gx : 0;
         a_lds[it] = (idx < 2 * C::HP) ? (pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
         a_half[it] = half;
     }
@@ -117,98 +120,95 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
 
     const int total = p.nchunks[0] + p.nchunks[1];
-    uint4 a_reg[C::A_ITEMS];
-    uint4 b_reg[C::B_ITEMS];
+    u32x4 a_reg[C::A_ITEMS];
+    u32x4 b_reg[C::B_ITEMS];
 
-    auto issue = [&](int i) {
-        const int s = (i >= p.nchunks[0]) ? 1 : 0;
-        const int chunk = s ? i - p.nchunks[0] : i;
-        const int taps = p.taps[s];
-        const T* in = (const T*)p.in[s];
-        const int cs = p.in_cs[s], co = p.in_co[s] + chunk * KCH;
-#pragma unroll
-        for (int it = 0; it < C::A_ITEMS; ++it) {
-            a_reg[it] = make_uint4(0, 0, 0, 0);
-            if (a_ok[it]) {
-                long pix = a_pix[it];
-                if (s && p.in0_blk) {   // rare: recompute the plain index for source 1
-                    const int idx = tid + it * 256, pp = idx >> 1;
-                    const int img = pp / C::HPI, rem = pp % C::HPI;
-                    pix = ((long)(img0 + img) * p.H + (y0 + rem / C::HW2 - 1)) * p.W + (x0 + rem % C::HW2 - 1);
-                }
-                a_reg[it] = *(const uint4*)(in + pix * cs + co + a_half[it] * EPS);
-            }
-        }
-        const char* wsrc = (const char*)p.w[s] + ((long)chunk * taps * p.n_pad + n0) * 32;
-#pragma unroll
-        for (int it = 0; it < C::B_ITEMS; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < taps * BN * 2) {
-                const int tap = idx / (BN * 2), rem = idx % (BN * 2);
-                b_reg[it] = *(const uint4*)(wsrc + (long)tap * p.n_pad * 32 + rem * 16);
-            }
-        }
-    };
-    auto commit = [&](int i) {
-        const int s = (i >= p.nchunks[0]) ? 1 : 0;
-        const int chunk = s ? i - p.nchunks[0] : i;
-        const int taps = p.taps[s];
-        const bool pro = (s == 0) && (p.prologue == PSSR_PRO_BN_RELU);
-#pragma unroll
-        for (int it = 0; it < C::A_ITEMS; ++it) {
-            if (a_lds[it] < 0) continue;
-            uint4 v = a_reg[it];
-            if (pro && a_ok[it]) {
-                const int c0 = chunk * KCH + a_half[it] * EPS;
-                float f[EPS];
-                X::unpack(v, f);
-#pragma unroll
-                for (int e = 0; e < EPS; e += 4) {
-                    const float4 sc = *(const float4*)(p.pro_scale + c0 + e);
-                    const float4 sh = *(const float4*)(p.pro_shift + c0 + e);
-                    f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);
-                    f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);
-                    f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);
-                    f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);
-                }
-                v = X::pack(f);
-            }
-            *(uint4*)(As + a_lds[it]) = v;
-        }
-#pragma unroll
-        for (int it = 0; it < C::B_ITEMS; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < taps * BN * 2) *(uint4*)(Bs + idx * 16) = b_reg[it];
-        }
-    };
-    auto compute = [&](int i) {
-        const int s = (i >= p.nchunks[0]) ? 1 : 0;
-        const int taps = p.taps[s];
-        for (int t = 0; t < taps; ++t) {
-            const int ky = (taps == 9) ? t / 3 : 1, kx = (taps == 9) ? t % 3 : 1;
-            uint4 af[C::MI], bf[C::NJ];
-#pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi) {
-                const int pa = a_p0[mi] + ky * C::HW2 + kx;
-                af[mi] = *(const uint4*)(As + pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4));
-            }
-#pragma unroll
-            for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const uint4*)(Bs + t * BN * 32 + b_off[nj]);
-#pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-                for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);
-        }
-    };
+    // NB: the three phases are macros, not lambdas: with lambdas hipcc keeps a_reg/b_reg in scratch.
+#define PSSR_ISSUE(I, TAPS)                                                                                       \
+    {                                                                                                             \
+        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
+        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
+        const T* in_ = (const T*)p.in[s_];                                                                        \
+        const int cs_ = p.in_cs[s_], co_ = p.in_co[s_] + chunk_ * KCH;                                            \
+        /* unconditional loads (out-of-image items read pixel 0 and are zeroed at commit): a guarded load   \
+           makes hipcc park the staging registers in scratch behind a vmcnt(0) each */                      \
+        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it)                                                 \
+            a_reg[it] = *(const u32x4*)(in_ + (s_ ? a_pix1[it] : a_pix[it]) * cs_ + co_ + a_half[it] * EPS);      \
+        const char* wsrc_ = (const char*)p.w[s_] + ((long)chunk_ * (TAPS) * p.n_pad + n0) * 32;                   \
+        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
+            int idx = tid + it * 256;                                                                             \
+            idx = idx < (TAPS) * BN * 2 ? idx : (TAPS) * BN * 2 - 1;                                              \
+            const int tap = idx / (BN * 2), rem = idx % (BN * 2);                                                 \
+            b_reg[it] = *(const u32x4*)(wsrc_ + (long)tap * p.n_pad * 32 + rem * 16);                             \
+        }                                                                                                         \
+    }
+#define PSSR_COMMIT(I, TAPS)                                                                                      \
+    {                                                                                                             \
+        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
+        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
+        const bool pro_ = (s_ == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                          \
+        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
+            if (a_lds[it] >= 0) {                                                                                 \
+                u32x4 v = a_reg[it];                                                                              \
+                if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                          \
+                if (pro_ && a_ok[it]) {                                                                           \
+                    const int c0 = chunk_ * KCH + a_half[it] * EPS;                                               \
+                    float f[EPS];                                                                                 \
+                    X::unpack(v, f);                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
+                        const float4 sc = *(const float4*)(p.pro_scale + c0 + e);                                 \
+                        const float4 sh = *(const float4*)(p.pro_shift + c0 + e);                                 \
+                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
+                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
+                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
+                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
+                    }                                                                                             \
+                    v = X::pack(f);                                                                               \
+                }                                                                                                 \
+                *(u32x4*)(As + a_lds[it]) = v;                                                                    \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
+            const int idx = tid + it * 256;                                                                       \
+            if (idx < (TAPS) * BN * 2) *(u32x4*)(Bs + idx * 16) = b_reg[it];                                      \
+        }                                                                                                         \
+    }
+#define PSSR_COMPUTE(TAPS)                                                                                        \
+    {                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < (TAPS); ++t) {                                                      \
+            const int ky = ((TAPS) == 9) ? t / 3 : 1, kx = ((TAPS) == 9) ? t % 3 : 1;                             \
+            u32x4 af[C::MI], bf[C::NJ];                                                                           \
+            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                \
+                const int pa = a_p0[mi] + ky * C::HW2 + kx;                                                       \
+                af[mi] = *(const u32x4*)(As + pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4));                            \
+            }                                                                                                     \
+            _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]); \
+            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
+                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
+        }                                                                                                         \
+    }
 
-    issue(0);
-    for (int i = 0; i < total; ++i) {
-        commit(i);
+    // source 0 (TAPS0 taps) then the optional 1x1 source 1; the loads of the next chunk fly during the MFMAs
+    const int n0c = p.nchunks[0];
+    PSSR_ISSUE(0, TAPS0)
+    for (int i = 0; i < n0c; ++i) {
+        PSSR_COMMIT(i, TAPS0)
         __syncthreads();
-        if (i + 1 < total) issue(i + 1);
-        compute(i);
+        if (i + 1 < n0c) PSSR_ISSUE(i + 1, TAPS0)
+        else if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
+        PSSR_COMPUTE(TAPS0)
         __syncthreads();
     }
+    for (int i = n0c; i < total; ++i) {
+        PSSR_COMMIT(i, 1)
+        __syncthreads();
+        if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
+        PSSR_COMPUTE(1)
+        __syncthreads();
+    }
+#undef PSSR_ISSUE
+#undef PSSR_COMMIT
+#undef PSSR_COMPUTE
 
     // ------------------------------------------------------------------ epilogue
     float* Es = (float*)smem;                       // [WM*32][BN] f32
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
-template <typename T, int BN, int GEO>
-int launch(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int BN, int GEO, int TAPS0>
+int launch_t(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<BN, GEO>;
     ConvArgs p = a;
     p.tiles_x = cdiv(a.W, C::TW);
@@ -329,12 +329,17 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
+}
+
+template <typename T, int BN, int GEO>
+int launch(const ConvArgs& a, hipStream_t s) {
+    return a.taps[0] == 9 ? launch_t<T, BN, GEO, 9>(a, s) : launch_t<T, BN, GEO, 1>(a, s);
 }
 
 template <typename T, int BN>
@@ -368,7 +373,7 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     PSSR_CHECK((d->in0_cstride * esz) % 16 == 0 && (d->in0_coff * esz) % 16 == 0, PSSR_ERR_ARG, "conv2d: in0 stride/offset not 16-byte aligned");
     PSSR_CHECK(d->in0_coff + d->cin0 <= d->in0_cstride, PSSR_ERR_ARG, "conv2d: in0 slice exceeds stride");
     if (d->cin1) {
-        PSSR_CHECK(d->in1 && d->w1 && d->cin1 % kch == 0 && (d->taps1 == 1 || d->taps1 == 9), PSSR_ERR_ARG, "conv2d: bad source 1");
+        PSSR_CHECK(d->in1 && d->w1 && d->cin1 % kch == 0 && d->taps1 == 1, PSSR_ERR_ARG, "conv2d: source 1 must be a 1x1 (or flat-K) source");
         PSSR_CHECK((d->in1_cstride * esz) % 16 == 0 && (d->in1_coff * esz) % 16 == 0 && d->in1_coff + d->cin1 <= d->in1_cstride, PSSR_ERR_ARG, "conv2d: in1 stride/offset");
     }
     if (d->epilogue == PSSR_EPI_FINAL) {

@@ -34,11 +34,12 @@ template <> struct Frag<bf16_t> {
     static constexpr int KP = 16;   // pixels per k-step
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     // `rowaddr0/1`: LDS byte address of (this lane's row q, its 4 columns) for reduction rows q and q+4
-    static __device__ __forceinline__ uint4 load(const char* a0, const char* a1) {
-        union { s16x4 v[2]; uint4 u; } r;
-        r.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-        r.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
-        return r.u;
+    static __device__ __forceinline__ u32x4 load(const char* a0, const char* a1) {
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1));
+        u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+        return r;
     }
 };
 
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
             const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
             const int ch = n0 + pc * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            u32x4 v = {0u, 0u, 0u, 0u};
             if (gi < p.N && gy < p.H && gx < p.W && ch < p.cout)
-                v = *(const uint4*)(dyp + pix_index(gi, gy, gx, p.H, p.W, p.dy_blk) * p.dy_cs + p.dy_co + ch);
-            *(uint4*)(Dy + sub * 128 * ROWB + m * ROWB + pin * 16) = v;
+                v = *(const u32x4*)(dyp + pix_index(gi, gy, gx, p.H, p.W, p.dy_blk) * p.dy_cs + p.dy_co + ch);
+            *(u32x4*)(Dy + sub * 128 * ROWB + m * ROWB + pin * 16) = v;
         }
         // ---- stage input halo tile: [cin sub][halo pixel][32 ch], BN+ReLU applied in flight
         for (int idx = tid; idx < AH_PIECES; idx += 256) {
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             const int hy = rem / HW2, hx = rem % HW2;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
             const int ch = k0 + pc * EPS;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            u32x4 v = {0u, 0u, 0u, 0u};
             if (gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ch < p.cin_pad) {
-                v = *(const uint4*)(inp + pix_index(gi, gy, gx, p.H, p.W, p.in_blk) * p.in_cs + p.in_co + ch);
+                v = *(const u32x4*)(inp + pix_index(gi, gy, gx, p.H, p.W, p.in_blk) * p.in_cs + p.in_co + ch);
                 if (p.prologue == PSSR_PRO_BN_RELU) {
                     float f[EPS];
                     X::unpack(v, f);
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                     v = X::pack(f);
                 }
             }
-            *(uint4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;
+            *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;
         }
         __syncthreads();
 
         // ---- multiply: 128/KP k-steps x taps
 
         for (int s = 0; s < 128 / KP; ++s) {
-            uint4 af;
+            u32x4 af;
             int hb[2];   // halo byte offsets of this lane's reduction rows (tap (0,0))
             if constexpr (sizeof(T) == 2) {
                 // ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 float a4[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) a4[t] = *(const float*)(dy_img + (m0 + t) * ROWB + r * 4);
-                af = make_uint4(__float_as_uint(a4[0]), __float_as_uint(a4[1]), __float_as_uint(a4[2]), __float_as_uint(a4[3]));
+                af = u32x4{__float_as_uint(a4[0]), __float_as_uint(a4[1]), __float_as_uint(a4[2]), __float_as_uint(a4[3])};
                 const int tx = m0 & (TW - 1), ty = (m0 >> TWL) & (TH - 1), img = m0 >> (TWL + THL);
                 hb[0] = (img * HPI + ty * HW2 + tx) * ROWB + r * 4;   // rows m0..m0+3 are consecutive in x when TW >= 4
                 hb[1] = 0;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             for (int t = 0; t < TAPS; ++t) {
                 const int ky = (TAPS == 9) ? t / 3 : 1, kx = (TAPS == 9) ? t % 3 : 1;
                 const int toff = (ky * HW2 + kx) * ROWB;
-                uint4 bf;
+                u32x4 bf;
                 if constexpr (sizeof(T) == 2) {
                     bf = Frag<bf16_t>::load(ah_img + hb[0] + toff, ah_img + hb[1] + toff);
                 } else {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                             b4[u] = *(const float*)(ah_img + (img * HPI + ty * HW2 + tx) * ROWB + r * 4 + toff);
                         }
                     }
-                    bf = make_uint4(__float_as_uint(b4[0]), __float_as_uint(b4[1]), __float_as_uint(b4[2]), __float_as_uint(b4[3]));
+                    bf = u32x4{__float_as_uint(b4[0]), __float_as_uint(b4[1]), __float_as_uint(b4[2]), __float_as_uint(b4[3])};
                 }
                 X::mma(acc[t], af, bf);
             }

@@ -64,6 +64,8 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
                            grad_scale)
+            for p in params:      # the kernel wrote the parameters behind torch's back: bump their version counters
+                torch.autograd.graph.increment_version(p)
         return loss
 
     def flat_grad(self, gi=0):
