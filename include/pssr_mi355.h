@@ -75,6 +75,11 @@ enum {
     PSSR_EPI_FINAL = 3       /* out_f32_nchw = (acc + bias)*out_scale + out_shift; any cout <= 32
                                 (Reconstruction.conv + "x*128+128", _blocks.py:17, resunet.py:95)  */
 };
+/* Per-channel f64 statistics are accumulated into PSSR_STAT_STRIPES interleaved copies
+ * (stats[stripe][2*C], stripe = workgroup index mod PSSR_STAT_STRIPES) so that thousands of workgroups do
+ * not serialise on 2*C addresses; the finalisers sum the stripes. */
+#define PSSR_STAT_STRIPES 32
+
 enum {
     PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
     PSSR_FLAG_STATS = 2   /* accumulate per-channel f64 sums into `stats`:
@@ -98,7 +103,7 @@ typedef struct pssr_conv_desc {
     const void* aux; int32_t aux_cstride, aux_coff;
     const float* aux_scale; const float* aux_shift;      /* [cout]                              */
     const float* aux_mean; const float* aux_invstd;      /* [cout] (DGRAD_MASK + STATS)         */
-    double* stats;              /* [2*cout], caller-zeroed                                     */
+    double* stats;              /* [PSSR_STAT_STRIPES][2*cout], caller-zeroed                  */
     /* "blocked" pixel order (log2 r, 0 = plain NHWC): pixel (y,x) of an r-times upsampled image
      * lives at ((y/r*W/r + x/r)*r*r + (y%r)*r + x%r), i.e. F.pixel_shuffle (_blocks.py:17) of an
      * NHWC tensor whose channels were ordered sub-pixel-major needs no data movement at all.    */
@@ -129,7 +134,7 @@ int pssr_conv2d_wgrad(const pssr_wgrad_desc* desc, pssr_stream_t stream);
  * NHWC tensor slices are passed as (pointer, channel stride, channel offset); C % 4 == 0.
  */
 
-/* stats[0:c] += sum, stats[c:2c] += sum of squares of (x*pre_scale + pre_shift) over N,H,W of an
+/* (striped, see PSSR_STAT_STRIPES) stats[0:c] += sum, stats[c:2c] += sum of squares of (x*pre_scale + pre_shift) over N,H,W of an
  * NCHW f32 tensor: batch statistics of ResUNet.norm on "x/128-1" (pssr/models/resunet.py:66-68). */
 int pssr_channel_stats_nchw(const float* x, int n, int c, int64_t hw, float pre_scale, float pre_shift,
                             double* stats, pssr_stream_t stream);
@@ -186,7 +191,7 @@ int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out,
                         void* dz, int dz_cs, int dz_co, double* stats, int64_t npix, int c, int dtype,
                         pssr_stream_t stream);
 
-/* out[c] += sum over pixels (bias gradients) */
+/* out[stripe][c] += sum over pixels (bias gradients); out holds PSSR_STAT_STRIPES x c doubles */
 int pssr_channel_sum_nhwc(const void* x, int cs, int co, int64_t npix, int c, double* out, int dtype,
                           pssr_stream_t stream);
 /* f32 NCHW -> NHWC in the compute dtype, scaled, channels [c, out_cs) zero (gradient of the output) */
@@ -194,7 +199,8 @@ int pssr_nchw_to_nhwc(const float* in, void* out, int n, int c, int64_t hw, int 
                       int dtype, pssr_stream_t stream);
 /* np.clip(x, 0, 255).astype(np.uint8): truncation toward zero (pssr/predict.py:245-246) */
 int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t stream);
-int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, pssr_stream_t stream);
+/* out[i] (+)= sum over `stripes` copies in[k*n + i] */
+int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, int stripes, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SSIM / MS-SSIM + Gaussian-L1 loss (pssr/util.py:10-52; pytorch_msssim 1.0.0 algorithm) on f32

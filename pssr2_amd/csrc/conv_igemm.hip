@@ -312,8 +312,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             float t1 = 0, t2 = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { t1 += Red[(w * BN + tid) * 2]; t2 += Red[(w * BN + tid) * 2 + 1]; }
-            atomicAdd(p.stats + n0 + tid, (double)t1);
-            atomicAdd(p.stats + p.cout + n0 + tid, (double)t2);
+            double* st = p.stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * p.cout;
+            atomicAdd(st + n0 + tid, (double)t1);
+            atomicAdd(st + p.cout + n0 + tid, (double)t2);
         }
     }
 }

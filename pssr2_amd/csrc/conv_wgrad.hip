@@ -209,9 +209,14 @@ int launch_t(WgradArgs p, hipStream_t stream) {
     p.n_tiles = p.tiles_x * p.tiles_y * p.tiles_i;
     p.co_tiles = cdiv(p.cout, CO_T); p.ci_tiles = cdiv(p.cin_pad, CI_T);
     const int slabs = p.co_tiles * p.ci_tiles;
-    int split = cdiv(1024, slabs);
-    if (split > p.n_tiles) split = p.n_tiles;
+    // Every workgroup ends with one f32 atomic add per slab element (147 KB for a 9-tap slab).  At the
+    // chip-wide float-atomic rate (~1.3 TB/s) that traffic hides behind the MFMAs only if a workgroup
+    // reduces over >= 8 pixel tiles first; below 256 workgroups the split is raised to fill the CUs.
+    int split = p.n_tiles / 8;
+    if (split > cdiv(1024, slabs)) split = cdiv(1024, slabs);      // ~1024 workgroups are plenty
     if (split < 1) split = 1;
+    if (slabs * split < 256) split = cdiv(256, slabs);
+    if (split > p.n_tiles) split = p.n_tiles;
     p.split = split;
     static bool attr_done = false;
     if (!attr_done) {

@@ -36,7 +36,8 @@ static int grid_for(long npix, const ChanMap& m) {
 // Block-level combine of NS per-thread sums of 4 channels each, then f64 atomics: dst[s*C + c]
 template <int NS>
 __device__ __forceinline__ void flush_sums(const ChanMap& m, int cg, float (*acc)[4], double* dst, int C, float* lds) {
-    // lds: [TPB][NS*4]
+    // lds: [TPB][NS*4]; dst is striped: [PSSR_STAT_STRIPES][NS*C]
+    dst += (long)(blockIdx.x % PSSR_STAT_STRIPES) * NS * C;
     if (m.cg_count <= TPB) {
         const int tid = threadIdx.x;
         if (m.active())
@@ -97,15 +98,20 @@ __global__ void nchw_stats_kernel(const float* __restrict__ x, int n, int c, lon
         if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { atomicAdd(stats + ch, (double)r1[0]); atomicAdd(stats + c + ch, (double)r2[0]); }
+    if (threadIdx.x == 0) {
+        double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+        atomicAdd(st + ch, (double)r1[0]); atomicAdd(st + c + ch, (double)r2[0]);
+    }
 }
 
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
                                    float* rmean, float* rvar, float* scale, float* shift, float* mean, float* invstd, int c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
-    const double mu = stats[i] / count;
-    double var = stats[c + i] / count - mu * mu;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < PSSR_STAT_STRIPES; ++k) { s1 += stats[(long)k * 2 * c + i]; s2 += stats[(long)k * 2 * c + c + i]; }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
     if (var < 0) var = 0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
@@ -133,7 +139,8 @@ __global__ void bn_bwd_coefs_kernel(const double* stats, double count, const flo
                                     float* A, float* B, float* Cc, float* dgamma, float* dbeta, int c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
-    const double s1 = stats[i], s2 = stats[c + i];
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < PSSR_STAT_STRIPES; ++k) { s1 += stats[(long)k * 2 * c + i]; s2 += stats[(long)k * 2 * c + c + i]; }
     const double c1 = s1 / count, c2 = s2 / count;
     const double g = gamma[i], is = invstd[i], mu = mean[i];
     A[i] = (float)(g * is);
@@ -196,7 +203,10 @@ __global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restr
         if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { atomicAdd(stats + ch, (double)r1[0]); atomicAdd(stats + c + ch, (double)r2[0]); }
+    if (threadIdx.x == 0) {
+        double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+        atomicAdd(st + ch, (double)r1[0]); atomicAdd(st + c + ch, (double)r2[0]);
+    }
 }
 
 template <typename T>
@@ -359,9 +369,12 @@ __global__ void clip_u8_kernel(const float* __restrict__ in, uint8_t* __restrict
     }
 }
 
-__global__ void f64_to_f32_kernel(const double* in, float* out, int n, int accumulate) {
+__global__ void f64_to_f32_kernel(const double* in, float* out, int n, int accumulate, int stripes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = accumulate ? out[i] + (float)in[i] : (float)in[i];
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < stripes; ++k) s += in[(long)k * n + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
 static inline int grid1d(long total) { long b = (total + TPB - 1) / TPB; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
@@ -518,9 +531,9 @@ int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t s) {
     return PSSR_OK;
 }
 
-int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, pssr_stream_t s) {
-    PSSR_CHECK(in && out && n > 0, PSSR_ERR_ARG, "f64_to_f32: bad args");
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)s, in, out, n, accumulate);
+int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, int stripes, pssr_stream_t s) {
+    PSSR_CHECK(in && out && n > 0 && stripes > 0, PSSR_ERR_ARG, "f64_to_f32: bad args");
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)s, in, out, n, accumulate, stripes);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

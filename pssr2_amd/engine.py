@@ -51,7 +51,7 @@ class _BNState:
     def __init__(self, c, f32: _Arena, f64: _Arena):
         self.c = c
         self.i32 = [f32.take(c) for _ in range(7)]      # scale shift mean invstd coefA coefB coefC
-        self.i64 = [f64.take(2 * c) for _ in range(2)]  # forward stats, backward stats
+        self.i64 = [f64.take(2 * c * ops.STAT_STRIPES) for _ in range(2)]  # forward stats, backward stats (striped)
 
     def bind(self, f32: _Arena, f64: _Arena):
         self.scale, self.shift, self.mean, self.invstd, self.ca, self.cb, self.cc = (f32.views[i] for i in self.i32)
@@ -249,7 +249,7 @@ class Engine:
         r = self.r
         b.g_hr = torch.zeros(n, p.h * r, p.w * r, 16, dtype=dt, device=device)
         b.dpre = torch.zeros(n, p.h, p.w, r * r * hid[0], dtype=dt, device=device)
-        b.sum64 = torch.zeros(max(16, r * r * hid[0]) + 2 * self.cin + 16, dtype=torch.float64, device=device)
+        b.sum64 = torch.zeros(ops.STAT_STRIPES * max(16, r * r * hid[0]), dtype=torch.float64, device=device)
         p.bwd = b
         return b
 
@@ -444,7 +444,7 @@ class Engine:
         bw.sum64.zero_()
         ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
         gb = torch.empty(16, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64[:16], gb)
+        ops.f64_to_f32(bw.sum64, gb)
         grads[id(rec.conv.bias)] = gb[:self.cout].clone()
         pre_hr = p.pre.view(n, H, W, h0)
         self._wgrad(p, grads, rec.conv, bw.g_hr, 16, pre_hr, h0, 9, in_blk=self.blk, hh=H, ww=W)
@@ -457,7 +457,7 @@ class Engine:
         bw.sum64.zero_()
         ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
         gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64[:cpre_n], gpb)
+        ops.f64_to_f32(bw.sum64, gpb)
         gb_pre = torch.empty_like(gpb)
         gb_pre[self.pre_perm_long] = gpb
         grads[id(rec.pre.bias)] = gb_pre

@@ -188,8 +188,11 @@ def clip_u8(x, out):
     L.check(L.lib().pssr_clip_u8(L.ptr(x), L.ptr(out), C.c_int64(x.numel()), L.stream_ptr()), "pssr_clip_u8")
 
 
-def f64_to_f32(src, dst, accumulate=False):
-    L.check(L.lib().pssr_f64_to_f32(L.ptr(src), L.ptr(dst), dst.numel(), int(accumulate), L.stream_ptr()), "pssr_f64_to_f32")
+STAT_STRIPES = 32     # PSSR_STAT_STRIPES
+
+
+def f64_to_f32(src, dst, accumulate=False, stripes=STAT_STRIPES):
+    L.check(L.lib().pssr_f64_to_f32(L.ptr(src), L.ptr(dst), dst.numel(), int(accumulate), stripes, L.stream_ptr()), "pssr_f64_to_f32")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ for name, H, W, ci, co, taps in layers:
     pw = ops.pack_conv_weight(w, code)
     out = torch.zeros(N, H, W, max(co, 4), device="cuda", dtype=dt)
     sc, sh = torch.ones(ci, device="cuda"), torch.zeros(ci, device="cuda")
-    stats = torch.zeros(2 * co, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(ops.STAT_STRIPES * 2 * co, dtype=torch.float64, device="cuda")
     bias = torch.zeros(co, device="cuda")
     fl = 2.0 * N * H * W * ci * co * taps
     if which in ("all", "fwd"):

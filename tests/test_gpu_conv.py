@@ -90,7 +90,7 @@ def test_conv_fused_prologue_epilogues(dt):
     xd = _nhwc(yprev, cin, dt)
     pw = ops.pack_conv_weight(wt.cuda(), code)
     out = torch.zeros(n, h, w, cout, dtype=dt, device="cuda")
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(ops.STAT_STRIPES, 2 * cout, dtype=torch.float64, device="cuda")
     ops.conv2d(xd, cin, pw, out, cout, n=n, h=h, w=w, bias=b.cuda(), pro_scale=scale.cuda(), pro_shift=shift.cuda(),
                flags=L.FLAG_STATS, stats=stats)
     torch.cuda.synchronize()
@@ -98,7 +98,7 @@ def test_conv_fused_prologue_epilogues(dt):
     rtol, atol = _tol(dt, cin * 9)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rtol, atol=atol * ref.abs().max().item())
     # statistics are those of the stored (rounded) values
-    s = stats.cpu().numpy()
+    s = stats.sum(0).cpu().numpy()      # statistics are striped over PSSR_STAT_STRIPES copies
     np.testing.assert_allclose(s[:cout], got.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
     np.testing.assert_allclose(s[cout:], (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
 
@@ -122,7 +122,7 @@ def test_conv_fused_prologue_epilogues(dt):
     mask = (yq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
     gref = torch.where(mask, da, torch.zeros_like(da))
     gd = torch.zeros(n, h, w, cin, dtype=dt, device="cuda")
-    st2 = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+    st2 = torch.zeros(ops.STAT_STRIPES, 2 * cin, dtype=torch.float64, device="cuda")
     ops.conv2d(_nhwc(dy, cout, dt), cout, ops.pack_conv_weight(wt.cuda(), code, mode=1), gd, cin, n=n, h=h, w=w,
                epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS, aux=xd, aux_scale=scale.cuda(), aux_shift=shift.cuda(),
                aux_mean=mean.cuda(), aux_invstd=invstd.cuda(), stats=st2)
@@ -131,7 +131,7 @@ def test_conv_fused_prologue_epilogues(dt):
     rtol, atol = _tol(dt, cout * 9)
     np.testing.assert_allclose(got.numpy(), gref.numpy(), rtol=rtol, atol=atol * gref.abs().max().item())
     xhat = (yq - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
-    s = st2.cpu().numpy()
+    s = st2.sum(0).cpu().numpy()
     np.testing.assert_allclose(s[:cin], got.double().sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(s[cin:], (got.double() * xhat.double()).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=2e-3)
 
