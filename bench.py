@@ -57,7 +57,9 @@ class ConvTimer:
 
     def remove(self):
         from pssr2_amd import ops
+        import pssr2_amd.engine as E
         ops.conv2d = self.orig
+        E.ops.conv2d = self.orig
 
     def summary(self):
         if not self.events:
@@ -98,6 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
     from pssr2_amd import distributed as D
@@ -124,46 +127,105 @@ def main():
     pool_n = 8                                           # distinct synthetic EM tiles per rank (tiled to the batch)
     pool = np.stack([synthetic_em_tile(rank * 100003 + i, hr_res) for i in range(pool_n)])
     pool = torch.from_numpy(pool).to(dev)                # uint8 [pool, 1, HR, HR], resident in HBM
-    gen = DevicePairGenerator(4, AdditiveGaussian(13, 0, 0), seed=1234)
-    if world > 1:
-        model._engine.attach_reducer()
-    state = {"tile": rank * 10 ** 9}
+    from pssr2_amd import ops
+    use_graph = not args.no_graph
+    # device-resident counters: nothing that changes from step to step is a kernel argument, so the
+    # whole step can be captured once into a hipGraph and replayed (the ~1000 launches per step
+    # otherwise cost more host time than the GPU needs to execute them)
+    tile_counter = torch.full((1,), rank * 10 ** 9, dtype=torch.int64, device=dev)
+    step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    ar = torch.arange(args.batch, device=dev)
+    gen = DevicePairGenerator(4, AdditiveGaussian(13, 0, 0), seed=1234, tile_counter=tile_counter)
+    opt.device_state = True
 
-    def batch_u8(step):
-        idx = (torch.arange(args.batch, device=dev) + step) % pool_n
-        return pool[idx]
+    def next_batch():
+        idx = (ar + step_dev) % pool_n
+        hr, lr = gen(pool[idx])
+        ops.counter_add(tile_counter, args.batch)
+        step_dev.add_(1)
+        return hr, lr
 
-    def train_step(step):
-        hr, lr = gen(batch_u8(step), tile_offset=state["tile"])
-        state["tile"] += args.batch
+    def fwd_bwd():
+        hr, lr = next_batch()
         hr_hat = model(lr)
         loss = loss_fn(hr_hat / 255, hr / 255)
         loss.backward()
-        opt.step()
-        opt.zero_grad()
         return loss
 
-    def infer_step(step):
-        _, lr = gen(batch_u8(step), tile_offset=state["tile"])
+    def reduce_and_update():
+        if world > 1:
+            flat = model._engine._flat_grad
+            torch.distributed.all_reduce(flat)
+            flat.mul_(1.0 / world)
+        opt.step()
+        opt.zero_grad()
+
+    def infer_body():
+        _, lr = next_batch()
         with torch.no_grad():
             y = model(lr)
             out = torch.empty(y.shape, dtype=torch.uint8, device=dev)
-            from pssr2_amd import ops
             ops.clip_u8(y, out)
         return out
 
+    graphs = {}
+
+    def capture(name, body):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        graphs[name] = g
+
     if args.mode == "train":
         model.train()
-        fn = train_step
+        if use_graph and world == 1:
+            def whole():
+                fwd_bwd()
+                reduce_and_update()
+            capture("step", whole)
+            fn = lambda s: graphs["step"].replay()
+        elif use_graph:
+            # data-parallel: the gradient all-reduce stays outside the captured region
+            def eager_step():
+                fwd_bwd()
+                reduce_and_update()
+            for _ in range(2):
+                eager_step()
+            capture("fwd_bwd", fwd_bwd)
+
+            def fn(s):
+                graphs["fwd_bwd"].replay()
+                reduce_and_update()
+        else:
+            if world > 1:
+                model._engine.attach_reducer()
+
+            def fn(s):
+                fwd_bwd()
+                if world > 1:
+                    opt.step(), opt.zero_grad()
+                else:
+                    reduce_and_update()
     else:
         model.eval()
-        fn = infer_step
+        if use_graph:
+            capture("infer", infer_body)
+            fn = lambda s: graphs["infer"].replay()
+        else:
+            fn = lambda s: infer_body()
 
     for s in range(args.warmup):
         fn(s)
     timer = ConvTimer()
-    if rank == 0 and args.dtype == "bf16":
-        timer.install()
+    if rank == 0 and args.dtype == "bf16" and not use_graph:
+        timer.install()       # eager mode: HIP events around every launch of the dominant kernel, in the timed region
 
     def barrier():
         if world > 1:
@@ -181,6 +243,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
 
+    measured_in = "timed region"
+    if rank == 0 and use_graph and args.dtype == "bf16":
+        # the timed region replayed a hipGraph; time the same kernels once more in an instrumented eager pass
+        timer.install()
+        eager = (lambda: (fwd_bwd(), opt.zero_grad())) if args.mode == "train" else infer_body
+        for _ in range(2):
+            eager()
+        torch.cuda.synchronize()
+        timer.remove()
+        measured_in = "instrumented eager pass after the timed region (the timed region replays the same kernels from a hipGraph)"
     if rank == 0:
         conv = timer.summary()
         tiles_per_s = world * args.batch * args.steps / elapsed
@@ -193,7 +265,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ResUNet 1-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
                                    f"AdditiveGaussian(13) device crappifier, MS-SSIM+L1 (mix .8), AdamW",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "step_compute": {"algorithmic_tflops": round(tiles_per_s * gflop_tile * scale / 1e3 / world, 2),
                              "frac_of_bf16_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / PEAK_BF16_TFLOPS, 4)},
         }
@@ -201,7 +274,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile> (3x3/1x1 conv fwd+dgrad)",
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1),
+                               "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1), "measured_in": measured_in,
                                "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()

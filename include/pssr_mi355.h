@@ -230,6 +230,11 @@ int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w
 int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                     pssr_stream_t stream);
+/* hipGraph-safe variant: `state` is a device int64[2] = {step, lr as f32 bits}; the call increments the
+ * step on the stream and the update kernel reads both from memory (nothing is frozen at capture). */
+int pssr_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t* state,
+                        float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                        pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pair generation / crappifiers (pssr/data.py:471-495, pssr/crappifiers.py).
@@ -246,11 +251,15 @@ int pssr_u8_to_f32(const uint8_t* in, float* out, int64_t n, pssr_stream_t strea
  * per tile; `noise` (f64, may be NULL) injects a pre-drawn field instead (exact-parity tests). */
 int pssr_crappify_gaussian(const float* in, float* out, int tiles, int64_t per_tile, float intensity,
                            float gain, float spread, uint64_t seed, uint64_t tile_offset,
-                           const double* noise, int flags, pssr_stream_t stream);
+                           const double* noise, int flags, const uint64_t* tile_counter,
+                           pssr_stream_t stream);
 /* Poisson (crappifiers.py:81-86): out = x*(1-i) + Poisson(max(x,0))*i + gain */
 int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_tile, float intensity,
                           float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags,
-                          pssr_stream_t stream);
+                          const uint64_t* tile_counter, pssr_stream_t stream);
+/* `tile_counter` (device, may be NULL) is added to tile_offset inside the kernel, so a captured hipGraph
+ * draws fresh noise on every replay; pssr_counter_add advances it on the stream. */
+int pssr_counter_add(uint64_t* counter, uint64_t inc, pssr_stream_t stream);
 /* Blur (crappifiers.py:122-124): per-plane separable Gaussian, edge replicate, radius int(4*sigma+.5) */
 int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int h, int w, float sigma,
                        float gain, int flags, pssr_stream_t stream);

@@ -112,7 +112,9 @@ __device__ __forceinline__ double tile_intensity(const Philox& ph, float intensi
 }
 
 __global__ void gaussian_noise_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, long per_tile, float intensity,
-                                      float gain, float spread, uint64_t seed, uint64_t tile_offset, const double* __restrict__ noise, int flags) {
+                                      float gain, float spread, uint64_t seed, uint64_t tile_offset, const double* __restrict__ noise, int flags,
+                                      const uint64_t* __restrict__ tile_counter) {
+    if (tile_counter) tile_offset += tile_counter[0];
     const long total = (long)tiles * per_tile;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long tile = i / per_tile, pix = i % per_tile;
@@ -156,7 +158,9 @@ __device__ double poisson_draw(const Philox& ph, uint64_t pix, double lam) {
 }
 
 __global__ void poisson_noise_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, long per_tile, float intensity,
-                                     float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags) {
+                                     float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags,
+                                     const uint64_t* __restrict__ tile_counter) {
+    if (tile_counter) tile_offset += tile_counter[0];
     const long total = (long)tiles * per_tile;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long tile = i / per_tile, pix = i % per_tile;
@@ -215,19 +219,29 @@ int pssr_u8_to_f32(const uint8_t* in, float* out, int64_t n, pssr_stream_t s) {
 }
 
 int pssr_crappify_gaussian(const float* in, float* out, int tiles, int64_t per_tile, float intensity, float gain, float spread,
-                           uint64_t seed, uint64_t tile_offset, const double* noise, int flags, pssr_stream_t s) {
+                           uint64_t seed, uint64_t tile_offset, const double* noise, int flags, const uint64_t* tile_counter,
+                           pssr_stream_t s) {
     PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_gaussian: bad args");
     hipLaunchKernelGGL(gaussian_noise_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
-                       intensity, gain, spread, seed, tile_offset, noise, flags);
+                       intensity, gain, spread, seed, tile_offset, noise, flags, tile_counter);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
 
 int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_tile, float intensity, float gain, float spread,
-                          uint64_t seed, uint64_t tile_offset, int flags, pssr_stream_t s) {
+                          uint64_t seed, uint64_t tile_offset, int flags, const uint64_t* tile_counter, pssr_stream_t s) {
     PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_poisson: bad args");
     hipLaunchKernelGGL(poisson_noise_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
-                       intensity, gain, spread, seed, tile_offset, flags);
+                       intensity, gain, spread, seed, tile_offset, flags, tile_counter);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+__global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { c[0] += inc; }
+
+int pssr_counter_add(uint64_t* counter, uint64_t inc, pssr_stream_t s) {
+    PSSR_CHECK(counter != nullptr, PSSR_ERR_ARG, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, counter, inc);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -3,8 +3,19 @@
 #include "common.h"
 
 namespace {
+__global__ void advance_kernel(long long* step) { step[0] += 1; }
+
+// `dev` (optional): device-resident [step (int64), lr (f32 bits in the next 4 bytes)] so that a captured
+// hipGraph replays with the right bias correction and learning rate
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                             const long long* dev) {
+    if (dev) {
+        const float st = (float)dev[0];
+        lr = __uint_as_float((unsigned)((const unsigned long long*)dev)[1]);
+        bc1 = 1.f - powf(b1, st);
+        bc2_sqrt = sqrtf(1.f - powf(b2, st));
+    }
     const long n4 = n / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 pv = ((float4*)p)[i], gv = ((const float4*)g)[i], mv = ((float4*)m)[i], vv = ((float4*)v)[i];
@@ -42,7 +53,20 @@ extern "C" int pssr_adamw_step(float* p, const float* g, float* m, float* v, int
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, grad_scale);
+                       weight_decay, bc1, bc2s, grad_scale, (const long long*)nullptr);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+extern "C" int pssr_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t* state, float beta1, float beta2,
+                                   float eps, float weight_decay, float grad_scale, pssr_stream_t s) {
+    PSSR_CHECK(p && g && m && v && state && n > 0, PSSR_ERR_ARG, "adamw_step_dev: bad args");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (long long*)state);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, 0.f, beta1, beta2, eps,
+                       weight_decay, 1.f, 1.f, grad_scale, (const long long*)state);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

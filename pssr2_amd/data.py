@@ -276,16 +276,17 @@ def synthetic_em_tile(index, res=512, channels=1):
 class DevicePairGenerator:
     """(HR, LR) batches from uint8 HR tiles already resident in HBM, entirely with HIP kernels."""
 
-    def __init__(self, lr_scale=4, crappifier=Poisson(), seed=0):
+    def __init__(self, lr_scale=4, crappifier=Poisson(), seed=0, tile_counter=None):
         self.lr_scale, self.crappifier, self.seed = lr_scale, crappifier, seed
+        self.tile_counter = tile_counter      # optional device uint64 added to tile_offset in-kernel (hipGraph replay)
 
     def _stage(self, x, spec, seed, tile_offset, flags):
         from . import ops
         kind, intensity, gain, spread = spec
         if kind == "gaussian":
-            return ops.crappify_gaussian(x, intensity, gain, spread, seed, tile_offset, flags)
+            return ops.crappify_gaussian(x, intensity, gain, spread, seed, tile_offset, flags, tile_counter=self.tile_counter)
         if kind == "poisson":
-            return ops.crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags)
+            return ops.crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, tile_counter=self.tile_counter)
         if kind == "blur":
             if spread > 0:
                 raise NotImplementedError("Blur(spread>0) has no device path")

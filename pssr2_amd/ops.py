@@ -253,21 +253,21 @@ def u8_to_f32(x):
     return out
 
 
-def crappify_gaussian(x, intensity, gain, spread, seed, tile_offset, flags, noise=None, out=None):
+def crappify_gaussian(x, intensity, gain, spread, seed, tile_offset, flags, noise=None, out=None, tile_counter=None):
     out = torch.empty_like(x) if out is None else out
     tiles = x.shape[0]
     L.check(L.lib().pssr_crappify_gaussian(L.ptr(x), L.ptr(out), tiles, C.c_int64(x.numel() // tiles), C.c_float(intensity), C.c_float(gain),
                                            C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), L.ptr(noise), flags,
-                                           L.stream_ptr()), "pssr_crappify_gaussian")
+                                           L.ptr(tile_counter), L.stream_ptr()), "pssr_crappify_gaussian")
     return out
 
 
-def crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, out=None):
+def crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, out=None, tile_counter=None):
     out = torch.empty_like(x) if out is None else out
     tiles = x.shape[0]
     L.check(L.lib().pssr_crappify_poisson(L.ptr(x), L.ptr(out), tiles, C.c_int64(x.numel() // tiles), C.c_float(intensity), C.c_float(gain),
-                                          C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), flags, L.stream_ptr()),
-            "pssr_crappify_poisson")
+                                          C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), flags, L.ptr(tile_counter),
+                                          L.stream_ptr()), "pssr_crappify_poisson")
     return out
 
 
@@ -278,3 +278,13 @@ def gaussian_blur(x, sigma, gain, flags):
     L.check(L.lib().pssr_gaussian_blur(L.ptr(x), L.ptr(tmp), L.ptr(out), planes, h, w, C.c_float(sigma), C.c_float(gain), flags,
                                        L.stream_ptr()), "pssr_gaussian_blur")
     return out
+
+
+def counter_add(counter, inc):
+    L.check(L.lib().pssr_counter_add(L.ptr(counter), C.c_uint64(inc), L.stream_ptr()), "pssr_counter_add")
+
+
+def adamw_step_dev(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    L.check(L.lib().pssr_adamw_step_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), L.ptr(state), C.c_float(beta1),
+                                        C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_float(grad_scale),
+                                        L.stream_ptr()), "pssr_adamw_step_dev")

@@ -14,6 +14,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = {}
+        self.device_state = False      # True: step count / lr are read from device memory (hipGraph capture)
 
     def _flatten(self, gi, group):
         """Move the group's parameters into one flat buffer (views keep shapes and identity)."""
@@ -62,8 +63,21 @@ class FusedAdamW(torch.optim.Optimizer):
                         g[o:o + p.numel()].copy_(p.grad.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
-            ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
-                           grad_scale)
+            if self.device_state:
+                # step counter and learning rate live on the device: safe to capture in a hipGraph
+                if "dev" not in st:
+                    import struct
+                    lr_bits = struct.unpack("<I", struct.pack("<f", float(group["lr"])))[0]
+                    st["dev"] = torch.tensor([st["step"] - 1, lr_bits], dtype=torch.int64, device=st["flat"].device)
+                    st["dev_lr"] = group["lr"]
+                elif st["dev_lr"] != group["lr"] and not torch.cuda.is_current_stream_capturing():
+                    import struct
+                    st["dev"][1] = struct.unpack("<I", struct.pack("<f", float(group["lr"])))[0]
+                    st["dev_lr"] = group["lr"]
+                ops.adamw_step_dev(st["flat"], g, st["m"], st["v"], st["dev"], b1, b2, group["eps"], group["weight_decay"], grad_scale)
+            else:
+                ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
+                               grad_scale)
             for p in params:      # the kernel wrote the parameters behind torch's back: bump their version counters
                 torch.autograd.graph.increment_version(p)
         return loss

@@ -24,6 +24,9 @@ def _gauss_1d(size: int, sigma: float):
     return (g / g.sum()).tolist()
 
 
+_CONST_CACHE = {}      # small per-shape device constants (kept out of hipGraph capture)
+
+
 class _SSIMLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, cfg):
@@ -53,8 +56,13 @@ class _SSIMLossFunction(torch.autograd.Function):
         for l in range(levels):
             hh, ww = dims[l]
             ops.ssim_level_fwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, sums[l * planes * 2:], l1_sum if l == 0 else None)
-        nvalid = torch.tensor([float((hh - k + 1) * (ww - k + 1)) for hh, ww in dims], dtype=torch.float64, device=dev)
-        lw = torch.tensor(list(lvl_w) if ms else [1.0], dtype=torch.float32, device=dev)
+        ckey = (tuple(dims), k, tuple(lvl_w) if ms else (1.0,), str(dev))
+        cached = _CONST_CACHE.get(ckey)
+        if cached is None:
+            cached = _CONST_CACHE[ckey] = (
+                torch.tensor([float((hh - k + 1) * (ww - k + 1)) for hh, ww in dims], dtype=torch.float64, device=dev),
+                torch.tensor(list(lvl_w) if ms else [1.0], dtype=torch.float32, device=dev))
+        nvalid, lw = cached
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         wts = torch.empty(levels * planes, dtype=torch.float32, device=dev)
         l1c = torch.empty(1, dtype=torch.float32, device=dev)
