@@ -1,0 +1,62 @@
+"""world_size-2 gloo tests of the data-parallel pieces (bucketed mean all-reduce, sampler sharding)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from pssr2_amd import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.is_distributed() and D.rank_world() == (rank, world)
+    sizes = [7, 64, 1, 300, 33, 5]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    flat = torch.zeros(tot)
+    red = D.GradReducer(flat, offs, sizes, bucket_bytes=256)
+    assert len(red.buckets) >= 3
+    for step in range(2):
+        red.begin()
+        flat.zero_()
+        # gradients become final in reverse parameter order, like a backward pass
+        for i in reversed(range(len(sizes))):
+            flat[offs[i]:offs[i] + sizes[i]] = float((rank + 1) * (i + 1) + step)
+            red.mark_ready([i])
+        red.finish()
+        for i, (o, n) in enumerate(zip(offs, sizes)):
+            expect = np.mean([(rk + 1) * (i + 1) + step for rk in range(world)])
+            assert torch.allclose(flat[o:o + n], torch.full((n,), float(expect))), (i, flat[o:o + n][:3], expect)
+    ts = [torch.full((3,), float(rank)), torch.full((2, 2), float(rank * 2))]
+    D.allreduce_mean_(ts)
+    assert torch.allclose(ts[0], torch.full((3,), 0.5)) and torch.allclose(ts[1], torch.full((2, 2), 1.0))
+    m = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        m.weight.fill_(float(rank + 1))
+    D.broadcast_module(m)
+    assert torch.all(m.weight == 1.0)
+    from pssr2_amd.data import _RandomIterIdx
+    mine = list(_RandomIterIdx(list(range(11)), rank=rank, world=world, shuffle_seed=0))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    assert len(gathered[0]) == len(gathered[1]) == 5 and not set(gathered[0]) & set(gathered[1])
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]

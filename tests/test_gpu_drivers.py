@@ -1,0 +1,83 @@
+"""train_paired / predict_images on the MI355X path: reference loop semantics and outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(n=6, res=64):
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import ArrayDataset, synthetic_em_tile
+    imgs = np.stack([synthetic_em_tile(i, res) for i in range(n)])
+    return ArrayDataset(imgs, hr_res=res, lr_scale=4, crappifier=AdditiveGaussian(5), val_split=0.34, rotation=True)
+
+
+def test_train_paired_loop_semantics(tmp_path):
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    torch.manual_seed(0)
+    ds = _dataset()
+    model = ResUNet(hidden=[16, 32])
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    seen = []
+    tl, vl = train_paired(model, ds, 2, torch.nn.MSELoss(), opt, epochs=2, device="cuda", log_frequency=1,
+                          checkpoint_dir=str(tmp_path / "ck"), collage_dir=str(tmp_path / "col"),
+                          callbacks=[lambda loc: seen.append(loc["batch_idx"])])
+    assert len(vl) == 2 and len(tl) == 4 and all(np.isfinite(tl)) and all(np.isfinite(vl))
+    assert seen == [0, 1, 0, 1]
+    cks = list((tmp_path / "ck").glob("checkpoint0_ResUNet_*.pth"))
+    assert len(cks) == 1 and not list((tmp_path / "ck").glob("checkpoint1_*"))
+    sd = torch.load(cks[0], weights_only=True)
+    assert "encoder.0.conv.0.weight" in sd and sd["reconstruction.pre.weight"].shape == (256, 17, 3, 3)
+    assert len(list((tmp_path / "col").glob("epoch*_loss*.png"))) == 2
+    assert next(model.parameters()).is_cuda            # model stays on the device, as upstream
+
+
+def test_training_reduces_loss_bf16_ssim():
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.util import SSIMLoss
+    from pssr2_amd.data import DevicePairGenerator, synthetic_em_tile
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    torch.manual_seed(1)
+    model = ResUNet(hidden=[16, 32, 64]).cuda().train()
+    model.compute_dtype = torch.bfloat16
+    opt = FusedAdamW(model.parameters(), lr=2e-3)
+    loss_fn = SSIMLoss(mix=0.8)
+    hr_u8 = torch.tensor(np.stack([synthetic_em_tile(i, 192) for i in range(4)])).cuda()
+    gen = DevicePairGenerator(4, AdditiveGaussian(5), seed=0)
+    losses = []
+    for it in range(30):
+        hr, lr = gen(hr_u8, tile_offset=4 * it)
+        loss = loss_fn(model(lr) / 255, hr / 255)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:3]), losses
+
+
+def test_predict_images_dict_and_pred_array(golden, tmp_path):
+    from pssr2_amd.data import SlidingArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import _pred_array, predict_images
+    g = golden("post.npz")
+    assert np.array_equal(_pred_array(torch.tensor(g["pred_in"]).cuda()), g["pred_out"])
+    torch.manual_seed(0)
+    model = ResUNet(hidden=[16, 32])
+    sheet = np.random.default_rng(0).integers(0, 256, size=(1, 100, 90)).astype(np.uint8)
+    ds = SlidingArrayDataset([sheet], hr_res=32, overlap=8)
+    assert len(ds) == 3 * 3
+    out = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None)
+    assert list(out.keys()) == [f"sheet0_{t}_0" for t in range(9)]
+    assert all(v.shape == (1, 128, 128) and v.dtype == np.uint8 for v in out.values())
+    # same tiles one by one give the same bytes (batching does not change eval-mode results)
+    single = predict_images(model, ds, device="cuda", batch_size=None, out_dir=None)
+    diff = max(int(np.abs(out[k].astype(int) - single[k].astype(int)).max()) for k in out)
+    assert diff <= 1
+    predict_images(model, ds, device="cuda", batch_size=4, out_dir=str(tmp_path / "p"), prefix="x")
+    assert len(list((tmp_path / "p").glob("x_sheet0_*_0.tif"))) == 9
+    with pytest.raises(ValueError):
+        predict_images(model, ds, device="cuda", norm=True, out_dir=None)
