@@ -25,6 +25,22 @@ TRAIN_GFLOP_PER_TILE = 189.91      # 31.652 GMAC fwd x 2 FLOP 
 FWD_GFLOP_PER_TILE = 63.30
 PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+DOMINANT_SYMBOL = "conv_igemm_kernelIDF16bLi128ELi0ELi9E"   # conv_igemm_kernel<bf16, BN=128, GEO=0 (8x16 tile), 9 taps>
+
+
+def pmc_traffic(mode):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, written by tools/summarize_profile.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no such profile has been committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            data = json.load(f)[mode]
+        for name, rec in data["kernels"].items():
+            if DOMINANT_SYMBOL in name:
+                return rec["hbm_bytes_per_launch"], data["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 class ConvTimer:
@@ -41,7 +57,7 @@ class ConvTimer:
 
         def timed(x, cin0, w0, out, cout, **kw):
             w = kw["w"]
-            dominant = cout > 64 and w > 8 and w0.dtype == 1
+            dominant = cout > 64 and w > 8 and w0.dtype == 1 and w0.taps == 9
             if not dominant:
                 return timer.orig(x, cin0, w0, out, cout, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -270,10 +286,12 @@ def main():
             "step_compute": {"algorithmic_tflops": round(tiles_per_s * gflop_tile * scale / 1e3 / world, 2),
                              "frac_of_bf16_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / PEAK_BF16_TFLOPS, 4)},
         }
+        traffic, traffic_src = pmc_traffic(args.mode)
         if conv:
-            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile> (3x3/1x1 conv fwd+dgrad)",
+            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile,9 taps> (3x3 conv fwd+dgrad, Cout>64)",
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                               "traffic_source": traffic_src,
                                "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1), "measured_in": measured_in,
                                "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2)}
         if not args.no_cpu_baseline and world == 1:
