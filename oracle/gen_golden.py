@@ -50,12 +50,17 @@ def import_reference():
     _stub("skimage.util", random_noise=_Absent())
     _stub("skimage.filters", gaussian=_Absent())
     _stub("skimage.metrics", peak_signal_noise_ratio=_Absent(), structural_similarity=_Absent())
-    _stub("timm"), _stub("timm.layers", LayerNorm2d=_Absent, EffectiveSEModule=_Absent, DropPath=_Absent,
+    # timm is absent: its four symbols used by pssr/models/_rdnet.py:11-12 are stood in for by the restatements in
+    # oracle/timm_recalled.py (PARITY UNPINNED for those four; everything else of RDNet / RDResUNet below is the
+    # reference's own code)
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from oracle import timm_recalled as TR
+    _stub("timm"), _stub("timm.layers", LayerNorm2d=TR.LayerNorm2d, EffectiveSEModule=TR.EffectiveSEModule, DropPath=TR.DropPath,
                          to_2tuple=_Absent(), trunc_normal_=_Absent())
-    _stub("timm.models", named_apply=_Absent())
+    _stub("timm.models", named_apply=TR.named_apply)
     _stub("skopt", gp_minimize=_Absent()), _stub("skopt.space", Dimension=_Absent)
     import pssr.crappifiers, pssr.data, pssr.predict, pssr.util          # noqa: E401,F401
-    import pssr.models._blocks, pssr.models.resunet                      # noqa: E401,F401
+    import pssr.models._blocks, pssr.models.resunet, pssr.models.rdresunet   # noqa: E401,F401
     return sys.modules["pssr"]
 
 
@@ -183,6 +188,72 @@ def gen_model(pssr):
     np.savez_compressed(OUT / "model.npz", **out)
 
 
+RD_CFGS = {
+    # name: (constructor kwargs, input hw, batch)
+    "rd_a": (dict(channels=1, hidden=[64, 64, 64, 32], scale=4, depth=3, rdnet_init=16, growth_rates=[8, 16, 16, 24],
+                  ds_blocks=[False, True, True, True], ese_blocks=[False, False, True, True], n_blocks=[2, 2, 2, 2]), 64, 2),
+    "rd_b": (dict(channels=[3, 1], hidden=[32, 32], scale=2, depth=1, rdnet_init=16, growth_rates=[8, 8, 16],
+                  ds_blocks=[False, False, True], ese_blocks=[True, False, True], n_blocks=[1, 2, 1]), 32, 3),
+}
+
+
+def gen_rdmodel(pssr):
+    """RDResUNet (reference code; timm layers restated, see import_reference) on two fixture-sized configurations:
+    eval / train outputs, running statistics and every parameter gradient of an MSE loss."""
+    from pssr.models.rdresunet import RDResUNet
+    out = {}
+    for name, (kw, hw, n) in RD_CFGS.items():
+        torch.manual_seed(11)
+        model = RDResUNet(**kw)
+        cin = model.norm.num_features
+        with torch.no_grad():
+            for mname, m in model.named_modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+                    m.running_mean.uniform_(-0.1, 0.1), m.running_var.uniform_(0.5, 1.5)
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+            for pname, p in model.named_parameters():
+                if pname.endswith(".gamma"):        # the 1e-6 initial layer scale would hide the dense blocks
+                    p.uniform_(0.5, 1.5)
+                if ".fc.bias" in pname:             # spread the ESE gate over both hard-sigmoid regimes
+                    p.uniform_(-2.0, 2.0)
+        x = torch.rand(n, cin, hw, hw) * 255
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            y_eval = model(x)
+        model.train()
+        y_train = model(x)
+        target = torch.rand_like(y_train) * 255
+        loss = torch.nn.functional.mse_loss(y_train / 255, target / 255)
+        loss.backward()
+        out[f"{name}_x"], out[f"{name}_target"] = x.numpy(), target.numpy()
+        out[f"{name}_y_eval"], out[f"{name}_y_train"] = y_eval.numpy(), y_train.detach().numpy()
+        out[f"{name}_loss"] = np.array(loss.item())
+        out[f"{name}_skips"] = np.array(model.skips)
+        out[f"{name}_repr"] = np.array(model.extra_repr())
+        for k, v in sd0.items():
+            out[f"{name}_sd/{k}"] = v.numpy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"{name}_sd_after/{k}"] = v.numpy()
+        for k, p in model.named_parameters():
+            out[f"{name}_grad/{k}"] = p.grad.numpy()
+    # default construction: key names, shapes, parameter count, creation (= RNG) order
+    torch.manual_seed(1234)
+    m = RDResUNet()
+    sd = m.state_dict()
+    out["default_keys"] = np.array(list(sd.keys()))
+    out["default_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+    out["default_nparams"] = np.array(sum(p.numel() for p in m.parameters()))
+    out["default_skips"] = np.array(m.skips)
+    out["default_repr"] = np.array(m.extra_repr())
+    out["default_sums"] = np.array([float(v.double().sum()) for v in sd.values()])
+    out["default_abssums"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    np.savez_compressed(OUT / "rdmodel.npz", **out)
+
+
 def gen_init(pssr):
     """Pins that constructing the build's ResUNet under the same torch seed reproduces the
     reference's default initialisation (parameter creation order and shapes)."""
@@ -294,7 +365,10 @@ if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(1)   # deterministic summation order for the fixtures
     pssr = import_reference()
-    for fn in (gen_bilinear, gen_pairs, gen_model, gen_init, gen_loss, gen_post, gen_train_trace):
+    only = sys.argv[1:]
+    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_train_trace):
+        if only and fn.__name__ not in only:
+            continue
         fn(pssr)
         print("wrote", fn.__name__)
     for f in sorted(OUT.glob("*.npz")):
