@@ -46,6 +46,9 @@ const char* pssr_last_error(void);
  * mode 1 (dgrad):    GEMM-K = output channels, GEMM-N = input channels of the range, taps flipped.
  * mode 2 (flat-K):   a KxK conv seen as 1x1 over im2col'ed channels: K index = (ci-ci_begin)*ks*ks + tap.
  * mode 3 (flat-K dgrad): the transpose of mode 2: GEMM-K = output channels, GEMM-N = flat index.
+ * mode 4 (space-to-depth): a KxK stride-K conv (RDNet transition, pssr/models/_rdnet.py:54-62) seen as 1x1 over the
+ *                    space-to-depth input written by pssr_layernorm2d_fwd(s2d=1): K index = tap*cpad + ci,
+ *                    cpad = cin rounded up to 16.   mode 5: its transpose (dgrad).
  * `k_pad` = GEMM-K rounded up to 16, `n_pad` = GEMM-N rounded up to 128 (zero filled).
  */
 int pssr_pack_conv_weight(const float* w_oihw, void* packed, int cout, int cin, int ks,
@@ -67,11 +70,13 @@ int pssr_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int cout, int
  * input tile is staged (prologue), and BatchNorm statistics / residual tail / ReLU-mask are
  * applied while the output tile is written (epilogue), so no normalised tensor is materialised.
  */
-enum { PSSR_PRO_NONE = 0, PSSR_PRO_BN_RELU = 1 };
+enum { PSSR_PRO_NONE = 0, PSSR_PRO_BN_RELU = 1,
+       PSSR_PRO_GELU = 2 /* in = gelu(in): nn.GELU between the two 1x1 convs of an RDNet block, pssr/models/_rdnet.py:185,200 */ };
 enum {
     PSSR_EPI_STORE = 0,      /* out = acc + bias                                             */
     PSSR_EPI_TAIL = 1,       /* out = relu(acc + bias + aux*aux_scale + aux_shift)  (ResBlock tail, _blocks.py:40) */
     PSSR_EPI_DGRAD_MASK = 2, /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
+    PSSR_EPI_DGRAD_GELU = 4, /* out = acc * gelu'(aux)   (GELU backward; with FLAG_STATS stats[0..cout) += sum out)  */
     PSSR_EPI_FINAL = 3       /* out_f32_nchw = (acc + bias)*out_scale + out_shift; any cout <= 32
                                 (Reconstruction.conv + "x*128+128", _blocks.py:17, resunet.py:95)  */
 };
@@ -173,6 +178,12 @@ int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const 
 
 /* F.max_pool2d(x, 2) (resunet.py:76) and its gradient; the gradient goes to the first maximum of
  * each window and is added to `dskip` (the skip-connection gradient of the same tensor, may be NULL). */
+/* Same with a third, optional gradient source: the patchify stem of RDNet (pssr_input_patchify below).  Any of
+ * dxcol_a / dxcol_b / dpatch may be NULL (not all three). */
+int pssr_input_norm_bwd2(const void* dxcol_a, const void* dxcol_b, int xc, const void* dpatch, int pc, int patch,
+                         const float* x_nchw, float pre_scale, float pre_shift, const float* mean, const float* invstd,
+                         int n, int c, int h, int w, double* stats, int dtype, pssr_stream_t stream);
+
 int pssr_maxpool2(const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
                   int n, int h, int w, int c, int dtype, pssr_stream_t stream);
 int pssr_maxpool2_bwd(const void* act, int act_cs, int act_co, const void* dpool, int dp_cs, int dp_co,
@@ -263,6 +274,59 @@ int pssr_counter_add(uint64_t* counter, uint64_t inc, pssr_stream_t stream);
 /* Blur (crappifiers.py:122-124): per-plane separable Gaussian, edge replicate, radius int(4*sigma+.5) */
 int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int h, int w, float sigma,
                        float gain, int flags, pssr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RDNet encoder of RDResUNet (pssr/models/_rdnet.py, pssr/models/rdresunet.py:84).  The 1x1 convolutions of its
+ * blocks and transitions run on pssr_conv2d / pssr_conv2d_wgrad (taps = 1; PSSR_PRO_GELU / PSSR_EPI_DGRAD_GELU fuse
+ * nn.GELU); the kernels below are the HBM-bound remainder.  torch.cat of the dense features (_rdnet.py:132-138,
+ * 169-170) is elided: every op reads / writes a channel slice (pointer, channel stride, channel offset).
+ */
+/* PatchifyStem input (_rdnet.py:110-111 seen as a 1x1 conv over patches): xpatch[n, y/ps, x/ps, ci*ps*ps + (y%ps)*ps + x%ps]
+ * = (x*pre_scale + pre_shift)*scale[ci] + shift[ci]  (input scaling + input BatchNorm, rdresunet.py:105-107); `pc` =
+ * channel stride (>= c*ps*ps, multiple of 16, rest zero).  Pack the stem weight with mode 2. */
+int pssr_input_patchify(const float* x_nchw, void* xpatch, int n, int c, int h, int w, int ps, int pc,
+                        float pre_scale, float pre_shift, const float* scale, const float* shift, int dtype,
+                        pssr_stream_t stream);
+/* Depthwise 7x7 conv, stride 1, zero padding 3 (nn.Conv2d(C, C, groups=C, kernel_size=7, padding=3), _rdnet.py:182,197).
+ * pssr_dwconv7_pack: torch weight [C,1,7,7] f32 -> [49][C] f32 (flip = 1: rotated by 180 degrees, for the input gradient).
+ * pssr_dwconv7: out (+)= bias + conv(in, packed)  (accumulate = 1 adds into `out`: the gradient of a dense-stage input
+ * that several blocks read).  pssr_dwconv7_wgrad: dw[C][49] += sum_pixels dy * shifted x (f32 atomics, caller zeroes). */
+int pssr_dwconv7_pack(const float* w, float* packed, int c, int flip, pssr_stream_t stream);
+int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, const float* bias, void* out, int out_cs,
+                 int out_co, int n, int h, int w, int c, int accumulate, int dtype, pssr_stream_t stream);
+int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h,
+                       int w, int c, int dtype, pssr_stream_t stream);
+/* timm LayerNorm2d (_rdnet.py:60,112,183,198): layer norm over the C channels of every pixel, eps inside the sqrt, affine.
+ * Channels [c, c_pad) of the output are written as zeros (K padding of the following 1x1 conv).  s2d = 1 writes the
+ * 2x2 space-to-depth layout out[n, y/2, x/2, ((y&1)*2 + (x&1))*c_pad + ch], which makes the stride-2 transition conv
+ * (_rdnet.py:56-62) a 1x1 conv over 4*c_pad channels (weights packed with mode 4).  mean / rstd: f32 [n*h*w], kept for
+ * the backward pass (NULL in inference).
+ * Backward: dx (+)= rstd*(g*gamma - mean_c(g*gamma) - xhat*mean_c(g*gamma*xhat)); stats[stripe][0..C) += sum g*xhat
+ * (dgamma), stats[stripe][C..2C) += sum g (dbeta), f64, PSSR_STAT_STRIPES stripes, caller-zeroed. */
+int pssr_layernorm2d_fwd(const void* in, int in_cs, int in_co, const float* gamma, const float* beta, float eps, void* out,
+                         int out_cs, int out_co, int s2d, int c_pad, int n, int h, int w, int c, float* mean, float* rstd,
+                         int dtype, pssr_stream_t stream);
+int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, const void* x, int x_cs, int x_co,
+                         const float* gamma, const float* mean, const float* rstd, void* dx, int dx_cs, int dx_co,
+                         int accumulate, int n, int h, int w, int c, double* stats, int dtype, pssr_stream_t stream);
+/* out[img][c] += scale * sum_{pixels of img} a*b (b may be NULL: plain sum): the spatial mean of timm's
+ * EffectiveSEModule (x.mean((2,3))) and the per-image reductions of its backward.  f32 atomics, caller zeroes. */
+int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c,
+                           float scale, float* out, int dtype, pssr_stream_t stream);
+/* EffectiveSEModule gate: u = fc(s) (1x1 conv on the [N, C] means), gate = hard_sigmoid(u) = relu6(u + 3)/6. */
+int pssr_ese_gate(const float* s_mean, const float* w_fc, const float* b_fc, int n, int c, float* u, float* gate,
+                  pssr_stream_t stream);
+/* out[p, c] = t[p, c] * gate[img][c] * gamma[c] + add[img][c]  (gate / add may be NULL): ESE gating and the layer
+ * scale of DenseBlock.forward (_rdnet.py:173-174) written at the block's channel offset of the stage buffer; with
+ * `add` it is also the backward of both. */
+int pssr_scale_nc(const void* t, int t_cs, int t_co, const float* gate, const float* gamma, const float* add, void* out,
+                  int out_cs, int out_co, int n, int hw, int c, int dtype, pssr_stream_t stream);
+/* Backward of gate + layer scale on the [N, C] side tensors, A[n][c] = sum_pixels dout*t (pssr_image_channel_dot):
+ * dgamma, d fc.bias, d fc.weight and add[n][c] = (1/hw) * W^T du, the per-image term of dt.  gate == NULL: plain
+ * layer scale (dgamma = sum_n A only). */
+int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float* gamma, const float* s_mean,
+                 const float* w_fc, int n, int c, int hw, float* du, float* dgamma, float* db_fc, float* dw_fc, float* add,
+                 pssr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,8 @@ _LIB_PATH = Path(__file__).resolve().parent / "libpssr_mi355.so"
 _lib = None
 
 F32, BF16 = 0, 1
-PRO_NONE, PRO_BN_RELU = 0, 1
-EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL = 0, 1, 2, 3
+PRO_NONE, PRO_BN_RELU, PRO_GELU = 0, 1, 2
+EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 FLAG_RELU, FLAG_STATS = 1, 2
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -81,6 +81,12 @@ __device__ __forceinline__ void load4(const bf16_t* p, float* v) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+// exact (erf) GELU of nn.GELU() (pssr/models/_rdnet.py:185,200) and its derivative
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float z) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
+}
+
 // Pixel linearisation: plain NHWC, or "blocked" order of an r-times (r = 1<<blk) upsampled image
 // (see pssr_conv_desc in include/pssr_mi355.h).
 __device__ __forceinline__ long pix_index(int gi, int gy, int gx, int H, int W, int blk) {

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
         const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
         const bool pro_ = (s_ == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                          \
+        const bool gelu_ = (s_ == 0) && (p.prologue == PSSR_PRO_GELU);                                            \
         _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
             if (a_lds[it] >= 0) {                                                                                 \
                 u32x4 v = a_reg[it];                                                                              \
@@ -163,6 +164,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                         f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
                         f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
                     }                                                                                             \
+                    v = X::pack(f);                                                                               \
+                }                                                                                                 \
+                if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                          \
+                    float f[EPS];                                                                                 \
+                    X::unpack(v, f);                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(As + a_lds[it]) = v;                                                                    \
@@ -276,6 +283,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 if (p.epi == PSSR_EPI_TAIL) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
+                } else if (p.epi == PSSR_EPI_DGRAD_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -384,8 +394,9 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
         PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 && d->out_coff + d->cout <= d->out_cstride, PSSR_ERR_ARG, "conv2d: out stride/offset");
     }
     PSSR_CHECK(d->n_pad % 128 == 0 && d->n_pad >= d->cout, PSSR_ERR_ARG, "conv2d: n_pad=%d", d->n_pad);
-    PSSR_CHECK(d->prologue == PSSR_PRO_NONE || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "conv2d: prologue needs scale/shift");
-    PSSR_CHECK(d->epilogue >= 0 && d->epilogue <= 3, PSSR_ERR_ARG, "conv2d: epilogue=%d", d->epilogue);
+    PSSR_CHECK(d->prologue >= 0 && d->prologue <= PSSR_PRO_GELU, PSSR_ERR_ARG, "conv2d: prologue=%d", d->prologue);
+    PSSR_CHECK(d->prologue != PSSR_PRO_BN_RELU || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "conv2d: prologue needs scale/shift");
+    PSSR_CHECK(d->epilogue >= 0 && d->epilogue <= 4, PSSR_ERR_ARG, "conv2d: epilogue=%d", d->epilogue);
     PSSR_CHECK(d->in0_blk >= 0 && d->out_blk >= 0 && d->aux_blk >= 0 && d->in0_blk <= 3 && d->out_blk <= 3 && d->aux_blk <= 3, PSSR_ERR_ARG, "conv2d: blocked order");
     {
         const int mb = d->in0_blk > d->out_blk ? (d->in0_blk > d->aux_blk ? d->in0_blk : d->aux_blk) : (d->out_blk > d->aux_blk ? d->out_blk : d->aux_blk);
@@ -394,6 +405,8 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     if (d->epilogue == PSSR_EPI_TAIL || d->epilogue == PSSR_EPI_DGRAD_MASK) {
         PSSR_CHECK(d->aux && d->aux_scale && d->aux_shift && d->aux_coff % 4 == 0 && d->aux_cstride % 4 == 0, PSSR_ERR_ARG, "conv2d: epilogue needs aux tensor");
     }
+    if (d->epilogue == PSSR_EPI_DGRAD_GELU)
+        PSSR_CHECK(d->aux && d->aux_coff % 4 == 0 && d->aux_cstride % 4 == 0, PSSR_ERR_ARG, "conv2d: GELU backward needs the pre-activation as aux");
     if (d->flags & PSSR_FLAG_STATS) {
         PSSR_CHECK(d->stats != nullptr, PSSR_ERR_ARG, "conv2d: stats buffer missing");
         PSSR_CHECK(d->epilogue != PSSR_EPI_DGRAD_MASK || (d->aux_mean && d->aux_invstd), PSSR_ERR_ARG, "conv2d: mask stats need mean/invstd");

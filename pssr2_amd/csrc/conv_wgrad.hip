@@ -120,6 +120,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                         f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);
                     }
                     v = X::pack(f);
+                } else if (p.prologue == PSSR_PRO_GELU) {
+                    float f[EPS];
+                    X::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);
+                    v = X::pack(f);
                 }
             }
             *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;
@@ -264,7 +270,8 @@ extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream)
     PSSR_CHECK(d->cout > 0 && (d->cout * esz) % 16 == 0, PSSR_ERR_ARG, "wgrad: cout=%d must fill whole 16-byte slots", d->cout);
     PSSR_CHECK((d->dy_cstride * esz) % 16 == 0 && (d->dy_coff * esz) % 16 == 0 && d->dy_coff + d->cout <= d->dy_cstride, PSSR_ERR_ARG, "wgrad: dy stride/offset");
     PSSR_CHECK((d->in_cstride * esz) % 16 == 0 && (d->in_coff * esz) % 16 == 0 && d->in_coff + d->cin_pad <= d->in_cstride, PSSR_ERR_ARG, "wgrad: in stride/offset");
-    PSSR_CHECK(d->prologue == PSSR_PRO_NONE || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "wgrad: prologue needs scale/shift");
+    PSSR_CHECK(d->prologue >= 0 && d->prologue <= PSSR_PRO_GELU, PSSR_ERR_ARG, "wgrad: prologue=%d", d->prologue);
+    PSSR_CHECK(d->prologue != PSSR_PRO_BN_RELU || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "wgrad: prologue needs scale/shift");
     PSSR_CHECK(d->dy_blk >= 0 && d->in_blk >= 0 && (d->h % (1 << d->dy_blk)) == 0 && (d->w % (1 << d->in_blk)) == 0, PSSR_ERR_ARG, "wgrad: blocked layout");
     WgradArgs a;
     a.N = d->n; a.H = d->h; a.W = d->w;

@@ -174,7 +174,8 @@ __global__ void input_im2col_kernel(const float* __restrict__ x, T* __restrict__
 
 // fold the gradient of xcol back onto the normalised input and reduce the input-BN parameter grads
 template <typename T>
-__global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restrict__ db, int xc, const float* __restrict__ x,
+__global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restrict__ db, int xc, const T* __restrict__ dp, int pc, int pk,
+                                      const float* __restrict__ x,
                                       float ps, float pb, const float* mean, const float* invstd, int n, int c, int h, int w, double* stats) {
     const int ch = blockIdx.y;
     const long hw = (long)h * w, total = (long)n * hw;
@@ -189,9 +190,13 @@ __global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restr
             const int qy = py - (tap / 3 - 1), qx = px - (tap % 3 - 1);
             if (qy >= 0 && qy < h && qx >= 0 && qx < w) {
                 const long q = ((long)img * h + qy) * w + qx;
-                g += (float)da[q * xc + ch * 9 + tap];
+                if (da) g += (float)da[q * xc + ch * 9 + tap];
                 if (db) g += (float)db[q * xc + ch * 9 + tap];
             }
+        }
+        if (dp) {   // patchify stem (pssr_input_patchify): pixel (py,px) is element ch*pk*pk + (py%pk)*pk + px%pk of patch (py/pk, px/pk)
+            const long q = ((long)img * (h / pk) + py / pk) * (w / pk) + px / pk;
+            g += (float)dp[q * pc + ch * pk * pk + (py % pk) * pk + px % pk];
         }
         const float xh = (fmaf(x[((long)img * c + ch) * hw + i % hw], ps, pb) - mean[ch]) * invstd[ch];
         s1 += g; s2 += g * xh;
@@ -436,16 +441,25 @@ int pssr_input_im2col(const float* x, void* xcol, int n, int c, int h, int w, in
     return PSSR_OK;
 }
 
-int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const float* x, float pre_scale, float pre_shift,
-                        const float* mean, const float* invstd, int n, int c, int h, int w, double* stats, int dtype, pssr_stream_t s) {
-    PSSR_CHECK(dxcol_a && x && mean && invstd && stats && xc >= 9 * c, PSSR_ERR_ARG, "input_norm_bwd: bad args");
+int pssr_input_norm_bwd2(const void* dxcol_a, const void* dxcol_b, int xc, const void* dpatch, int pc, int patch, const float* x,
+                         float pre_scale, float pre_shift, const float* mean, const float* invstd, int n, int c, int h, int w, double* stats,
+                         int dtype, pssr_stream_t s) {
+    PSSR_CHECK((dxcol_a || dxcol_b || dpatch) && x && mean && invstd && stats, PSSR_ERR_ARG, "input_norm_bwd: bad args");
+    PSSR_CHECK(!(dxcol_a || dxcol_b) || xc >= 9 * c, PSSR_ERR_ARG, "input_norm_bwd: xc=%d", xc);
+    PSSR_CHECK(!dpatch || (patch > 0 && pc >= c * patch * patch && h % patch == 0 && w % patch == 0), PSSR_ERR_ARG, "input_norm_bwd: patch gradient layout");
     const long total = (long)n * h * w;
     int gx = (int)((total + TPB * 4 - 1) / (TPB * 4));
     if (gx > 512) gx = 512;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(input_norm_bwd_kernel<T>, dim3(gx, c), dim3(TPB), 0, (hipStream_t)s, (const T*)dxcol_a, (const T*)dxcol_b, xc, x,
-                                         pre_scale, pre_shift, mean, invstd, n, c, h, w, stats));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(input_norm_bwd_kernel<T>, dim3(gx, c), dim3(TPB), 0, (hipStream_t)s, (const T*)dxcol_a, (const T*)dxcol_b, xc,
+                                         (const T*)dpatch, pc, patch > 0 ? patch : 1, x, pre_scale, pre_shift, mean, invstd, n, c, h, w, stats));
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
+}
+
+int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const float* x, float pre_scale, float pre_shift,
+                        const float* mean, const float* invstd, int n, int c, int h, int w, double* stats, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dxcol_a != nullptr, PSSR_ERR_ARG, "input_norm_bwd: bad args");
+    return pssr_input_norm_bwd2(dxcol_a, dxcol_b, xc, nullptr, 0, 0, x, pre_scale, pre_shift, mean, invstd, n, c, h, w, stats, dtype, s);
 }
 
 #define CHECK_REF(name, cs, co, c)                                                                               \

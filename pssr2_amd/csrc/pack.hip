@@ -23,10 +23,20 @@ struct PackMap {
             if (k >= ci_count * kk || n >= cout) return -1;
             const int co = n_perm ? n_perm[n] : n;
             return ((long)co * cin + ci_begin) * kk + k;
-        } else {                  // flat-K dgrad: K = co, N = (ci - ci_begin)*kk + tap', single tap
+        } else if (mode == 3) {   // flat-K dgrad: K = co, N = (ci - ci_begin)*kk + tap', single tap
             if (k >= cout || n >= ci_count * kk) return -1;
             const int co = n_perm ? n_perm[k] : k;
             return ((long)co * cin + ci_begin) * kk + n;
+        } else if (mode == 4) {   // space-to-depth: K = tap'*cpad + ci (cpad = cin rounded up to 16), N = co, single tap
+            const int cpad = (cin + 15) / 16 * 16;
+            const int tp = k / cpad, ci = k % cpad;
+            if (tp >= kk || ci >= cin || n >= cout) return -1;
+            return ((long)n * cin + ci) * kk + tp;
+        } else {                  // space-to-depth dgrad: K = co, N = tap'*cpad + ci
+            const int cpad = (cin + 15) / 16 * 16;
+            const int tp = n / cpad, ci = n % cpad;
+            if (tp >= kk || ci >= cin || k >= cout) return -1;
+            return ((long)k * cin + ci) * kk + tp;
         }
     }
 };
@@ -69,12 +79,14 @@ extern "C" int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int 
 extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int cin, int ks, int ci_begin, int ci_count,
                                      int mode, const int32_t* n_perm, int k_pad, int n_pad, int dtype, pssr_stream_t stream) {
     PSSR_CHECK(w && packed, PSSR_ERR_ARG, "pack: null pointer");
-    PSSR_CHECK(ks == 1 || ks == 3, PSSR_ERR_ARG, "pack: ks=%d", ks);
-    PSSR_CHECK(mode >= 0 && mode <= 3, PSSR_ERR_ARG, "pack: mode=%d", mode);
+    PSSR_CHECK(ks >= 1 && ks <= 3, PSSR_ERR_ARG, "pack: ks=%d", ks);
+    PSSR_CHECK(mode >= 0 && mode <= 5, PSSR_ERR_ARG, "pack: mode=%d", mode);
+    PSSR_CHECK(ks != 2 || mode >= 2, PSSR_ERR_ARG, "pack: a 2x2 (stride-2) kernel is only consumed in a flat-K / space-to-depth mode");
     PSSR_CHECK(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= cin, PSSR_ERR_ARG, "pack: channel range");
     PSSR_CHECK(k_pad % 16 == 0 && n_pad % 128 == 0, PSSR_ERR_ARG, "pack: k_pad=%d n_pad=%d", k_pad, n_pad);
-    const int gk = mode == 0 ? ci_count : (mode == 1 || mode == 3) ? cout : ci_count * ks * ks;
-    const int gn = mode == 1 ? ci_count : mode == 3 ? ci_count * ks * ks : cout;
+    const int s2dk = ks * ks * ((cin + 15) / 16 * 16);
+    const int gk = mode == 0 ? ci_count : (mode == 1 || mode == 3 || mode == 5) ? cout : mode == 4 ? s2dk : ci_count * ks * ks;
+    const int gn = mode == 1 ? ci_count : mode == 3 ? ci_count * ks * ks : mode == 5 ? s2dk : cout;
     PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
     PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
     const long total = (long)m.taps * k_pad * n_pad;
@@ -92,8 +104,8 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
 extern "C" int pssr_unpack_conv_wgrad(const float* dwp, float* dw, int cout, int cin, int ks, int ci_begin, int ci_count,
                                       int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
     PSSR_CHECK(dwp && dw, PSSR_ERR_ARG, "unpack: null pointer");
-    PSSR_CHECK(mode == 0 || mode == 2, PSSR_ERR_ARG, "unpack: mode=%d", mode);
-    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode == 2 ? 1 : ks * ks, n_perm};
+    PSSR_CHECK(mode == 0 || mode == 2 || mode == 4, PSSR_ERR_ARG, "unpack: mode=%d", mode);
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
     const long total = (long)cout * m.taps * k_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwp, dw, m, k_pad, accumulate, total);

@@ -1,0 +1,552 @@
+// HBM-bound kernels of the RDNet encoder (pssr/models/_rdnet.py): patchify stem input, depthwise 7x7
+// convolution (forward / input gradient / weight gradient), LayerNorm2d over the channels of every
+// pixel (forward / backward, optionally writing the 2x2 space-to-depth layout that turns the
+// following stride-2 transition conv into a 1x1 conv), the Effective-SE gate and the layer-scale.
+// All tensors are NHWC slices (pointer, channel stride, channel offset): the dense-concatenation of
+// RDNet (torch.cat of all previous features, _rdnet.py:132-138) is elided by writing every new
+// feature at its channel offset of one buffer per stage.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct Ref { const void* p; int cs, co; };
+struct MRef { void* p; int cs, co; };
+template <typename T> __device__ __forceinline__ const T* at(const Ref& r, long pix, int c) { return (const T*)r.p + pix * r.cs + r.co + c; }
+template <typename T> __device__ __forceinline__ T* at(const MRef& r, long pix, int c) { return (T*)r.p + pix * r.cs + r.co + c; }
+
+static inline int grid1d(long total, int cap = 8192) { long b = (total + TPB - 1) / TPB; return (int)(b < cap ? (b > 0 ? b : 1) : cap); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// xpatch[n, oy, ox, ci*ps*ps + dy*ps + dx] = bn(x[n, ci, oy*ps+dy, ox*ps+dx]*pre_scale + pre_shift)
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ xp, int n, int c, int h, int w, int ps, int pc,
+                                float prs, float prb, const float* scale, const float* shift) {
+    const int ho = h / ps, wo = w / ps, kk = ps * ps;
+    const long total = (long)n * ho * wo * pc;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % pc;
+        long pix = i / pc;
+        const int ox = pix % wo; pix /= wo;
+        const int oy = pix % ho;
+        const int img = pix / ho;
+        float v = 0.f;
+        if (k < c * kk) {
+            const int ch = k / kk, tap = k % kk;
+            const int sy = oy * ps + tap / ps, sx = ox * ps + tap % ps;
+            v = fmaf(fmaf(x[(((long)img * c + ch) * h + sy) * w + sx], prs, prb), scale[ch], shift[ch]);
+        }
+        xp[i] = (T)v;
+    }
+}
+
+// packed depthwise weight: wp[tap][c] = w[c][flip ? 48 - tap : tap]
+__global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int c, int flip) {
+    const int total = 49 * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = i % c, tap = i / c;
+        wp[i] = w[ch * 49 + (flip ? 48 - tap : tap)];
+    }
+}
+
+// depthwise 7x7, stride 1, zero padding 3: out[p, c] (+)= bias[c] + sum_tap in[p + tap - 3, c] * wp[tap][c]
+template <typename T>
+__global__ void dwconv7_kernel(Ref in, const float* __restrict__ wp, const float* __restrict__ bias, MRef out, int n, int h, int w, int c,
+                               int accumulate) {
+    const int cg = c / 4;
+    const long total = (long)n * h * w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        long pix = i / cg;
+        const int px = pix % w;
+        const int py = (pix / w) % h;
+        const long img_base = (pix / ((long)w * h)) * h * w;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) load4(bias + c0, acc);
+        for (int ky = 0; ky < 7; ++ky) {
+            const int sy = py + ky - 3;
+            if (sy < 0 || sy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int sx = px + kx - 3;
+                if (sx < 0 || sx >= w) continue;
+                float v[4];
+                load4(at<T>(in, img_base + (long)sy * w + sx, c0), v);
+                const float4 wv = *(const float4*)(wp + (ky * 7 + kx) * c + c0);
+                acc[0] = fmaf(v[0], wv.x, acc[0]); acc[1] = fmaf(v[1], wv.y, acc[1]);
+                acc[2] = fmaf(v[2], wv.z, acc[2]); acc[3] = fmaf(v[3], wv.w, acc[3]);
+            }
+        }
+        if (accumulate) {
+            float o[4];
+            load4(at<T>(out, pix, c0), o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += o[e];
+        }
+        store4(at<T>(out, pix, c0), acc);
+    }
+}
+
+// dW[c][ky*7+kx] += sum_p dy[p, c] * x[p + (ky-3, kx-3), c]; blockIdx.y = ky, a thread keeps one channel group
+template <typename T>
+__global__ void dwconv7_wgrad_kernel(Ref dy, Ref x, float* __restrict__ dw, int n, int h, int w, int c) {
+    __shared__ float lds[TPB * 28];
+    const int cgc = c / 4;
+    const int ky = blockIdx.y;
+    const long npix = (long)n * h * w;
+    const int ppb = cgc <= TPB ? TPB / cgc : 1;
+    for (int cg0 = 0; cg0 < cgc; cg0 += TPB) {       // one pass when c <= 1024
+        const int cg = cg0 + (cgc <= TPB ? (int)threadIdx.x % cgc : (int)threadIdx.x);
+        const int pl = cgc <= TPB ? (int)threadIdx.x / cgc : 0;
+        const bool active = cg < cgc && pl < ppb;
+        float acc[7][4];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+        if (active) {
+            for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
+                const int px = pix % w;
+                const int py = (pix / w) % h;
+                const int sy = py + ky - 3;
+                if (sy < 0 || sy >= h) continue;
+                float g[4];
+                load4(at<T>(dy, pix, cg * 4), g);
+                const long row = pix - px + (long)(ky - 3) * w;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int sx = px + kx - 3;
+                    if (sx < 0 || sx >= w) continue;
+                    float v[4];
+                    load4(at<T>(x, row + sx, cg * 4), v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[kx][e] = fmaf(g[e], v[e], acc[kx][e]);
+                }
+            }
+        }
+        // combine the pixel lanes of the block, then one atomic per (channel, tap) per block
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[threadIdx.x * 28 + k * 4 + e] = active ? acc[k][e] : 0.f;
+        __syncthreads();
+        if (cgc <= TPB) {
+            if ((int)threadIdx.x < cgc) {
+                for (int k = 0; k < 7; ++k)
+                    for (int e = 0; e < 4; ++e) {
+                        float t = 0.f;
+                        for (int q = 0; q < ppb; ++q) t += lds[(q * cgc + threadIdx.x) * 28 + k * 4 + e];
+                        atomicAdd(dw + (long)(threadIdx.x * 4 + e) * 49 + ky * 7 + k, t);
+                    }
+            }
+        } else if (active) {
+            for (int k = 0; k < 7; ++k)
+                for (int e = 0; e < 4; ++e) atomicAdd(dw + (long)(cg * 4 + e) * 49 + ky * 7 + k, acc[k][e]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm2d: one wave per pixel, lane l holds channel groups l, l+64, ...  (C <= 256*LN_MAXIT)
+constexpr int LN_MAXIT = 8;
+
+__device__ __forceinline__ void ln_out_pos(long pix, int h, int w, int s2d, int cpad, long& opix, int& cbase) {
+    if (!s2d) { opix = pix; cbase = 0; return; }
+    const int px = pix % w;
+    const int py = (pix / w) % h;
+    const long img = pix / ((long)w * h);
+    opix = (img * (h / 2) + py / 2) * (w / 2) + px / 2;
+    cbase = ((py & 1) * 2 + (px & 1)) * cpad;
+}
+
+template <typename T>
+__global__ void ln_fwd_kernel(Ref in, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, MRef out, int s2d, int cpad,
+                              long npix, int h, int w, int c, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), nw = (long)gridDim.x * (TPB / 64);
+    const float inv_c = 1.f / (float)c;
+    for (long pix = wid; pix < npix; pix += nw) {
+        float v[LN_MAXIT][4];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+                load4(at<T>(in, pix, c0), v[it]);
+                s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+            }
+        }
+        const float mu = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mu; q = fmaf(d, d, q); }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * inv_c + eps);
+        long opix; int cbase;
+        ln_out_pos(pix, h, w, s2d, cpad, opix, cbase);
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+                float g[4], b[4], o[4];
+                load4(gamma + c0, g); load4(beta + c0, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf((v[it][e] - mu) * rs, g[e], b[e]);
+                store4(at<T>(out, opix, cbase + c0), o);
+            } else if (c0 < cpad) {
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store4(at<T>(out, opix, cbase + c0), z);
+            }
+        }
+        if (lane == 0 && mean) { mean[pix] = mu; rstd[pix] = rs; }
+    }
+}
+
+// dx (+)= rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat));  stats += [sum_p g*xhat | sum_p g]
+template <typename T>
+__global__ void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, MRef dx, int accumulate, long npix, int h, int w, int c, double* stats) {
+    __shared__ float lds[(TPB / 64) * 64 * 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * (TPB / 64) + wv, nw = (long)gridDim.x * (TPB / 64);
+    const float inv_c = 1.f / (float)c;
+    float dgam[LN_MAXIT][4], dbet[LN_MAXIT][4];
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dgam[it][e] = dbet[it][e] = 0.f;
+    for (long pix = wid; pix < npix; pix += nw) {
+        const float mu = mean[pix], rs = rstd[pix];
+        long opix; int cbase;
+        ln_out_pos(pix, h, w, s2d, cpad, opix, cbase);
+        float xh[LN_MAXIT][4], gg[LN_MAXIT][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+                float xv[4], gv[4], gm[4];
+                load4(at<T>(x, pix, c0), xv); load4(at<T>(g, opix, cbase + c0), gv); load4(gamma + c0, gm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[it][e] = (xv[e] - mu) * rs;
+                    gg[it][e] = gv[e] * gm[e];
+                    s1 += gg[it][e];
+                    s2 = fmaf(gg[it][e], xh[it][e], s2);
+                    dgam[it][e] = fmaf(gv[e], xh[it][e], dgam[it][e]);
+                    dbet[it][e] += gv[e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gg[it][e] - m1 - xh[it][e] * m2);
+                if (accumulate) {
+                    float prev[4];
+                    load4(at<T>(dx, pix, c0), prev);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += prev[e];
+                }
+                store4(at<T>(dx, pix, c0), o);
+            }
+        }
+    }
+    // block combine (4 waves) per iteration slice, then one f64 atomic per channel per block into a stripe
+    double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+        if (64 * it * 4 >= c) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lds[(wv * 64 + lane) * 8 + e] = dgam[it][e]; lds[(wv * 64 + lane) * 8 + 4 + e] = dbet[it][e]; }
+        __syncthreads();
+        if (wv == 0) {
+            const int c0 = (lane + 64 * it) * 4;
+            if (c0 < c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int q = 0; q < TPB / 64; ++q) { a += lds[(q * 64 + lane) * 8 + e]; b += lds[(q * 64 + lane) * 8 + 4 + e]; }
+                    atomicAdd(st + c0 + e, (double)a);
+                    atomicAdd(st + c + c0 + e, (double)b);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[img][c] += scale * sum_{p in img} a[p, c] * (b ? b[p, c] : 1);  grid = (chunks, images)
+template <typename T>
+__global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scale, float* __restrict__ out) {
+    __shared__ float lds[TPB * 4];
+    const int cgc = c / 4, img = blockIdx.y;
+    const int ppb = cgc <= TPB ? TPB / cgc : 1;
+    const long base = (long)img * hw;
+    for (int cg0 = 0; cg0 < cgc; cg0 += TPB) {
+        const int cg = cg0 + (cgc <= TPB ? (int)threadIdx.x % cgc : (int)threadIdx.x);
+        const int pl = cgc <= TPB ? (int)threadIdx.x / cgc : 0;
+        const bool active = cg < cgc && pl < ppb;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (int p = blockIdx.x * ppb + pl; p < hw; p += gridDim.x * ppb) {
+                float av[4];
+                load4(at<T>(a, base + p, cg * 4), av);
+                if (b.p) {
+                    float bv[4];
+                    load4(at<T>(b, base + p, cg * 4), bv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[e], bv[e], acc[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += av[e];
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[threadIdx.x * 4 + e] = active ? acc[e] : 0.f;
+        __syncthreads();
+        if (cgc <= TPB) {
+            if ((int)threadIdx.x < cgc)
+                for (int e = 0; e < 4; ++e) {
+                    float t = 0.f;
+                    for (int q = 0; q < ppb; ++q) t += lds[(q * cgc + threadIdx.x) * 4 + e];
+                    atomicAdd(out + (long)img * c + threadIdx.x * 4 + e, t * scale);
+                }
+        } else if (active) {
+            for (int e = 0; e < 4; ++e) atomicAdd(out + (long)img * c + cg * 4 + e, acc[e] * scale);
+        }
+        __syncthreads();
+    }
+}
+
+// Effective-SE gate: u[n][co] = b[co] + sum_ci W[co][ci] * s[n][ci];  gate = relu6(u + 3) / 6
+__global__ void ese_gate_kernel(const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ b, int n, int c,
+                                float* __restrict__ u, float* __restrict__ gate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int img = i / c, co = i % c;
+    float acc = b[co];
+    for (int ci = 0; ci < c; ++ci) acc = fmaf(w[(long)co * c + ci], s[(long)img * c + ci], acc);
+    u[i] = acc;
+    gate[i] = fminf(fmaxf(acc + 3.f, 0.f), 6.f) * (1.f / 6.f);
+}
+
+// out[p, c] = t[p, c] * (gate ? gate[img][c] : 1) * gamma[c] + (add ? add[img][c] : 0)
+template <typename T>
+__global__ void scale_nc_kernel(Ref t, const float* __restrict__ gate, const float* __restrict__ gamma, const float* __restrict__ add, MRef out,
+                                long npix, int hw, int c) {
+    const int cg = c / 4;
+    const long total = npix * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        const long pix = i / cg;
+        const long img = pix / hw;
+        float v[4], gm[4], gt[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(at<T>(t, pix, c0), v); load4(gamma + c0, gm);
+        if (gate) load4(gate + img * c + c0, gt);
+        if (add) load4(add + img * c + c0, ad);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gt[e] * gm[e], ad[e]);
+        store4(at<T>(out, pix, c0), v);
+    }
+}
+
+// ESE / layer-scale backward on the [N, C] side tensors.  A[n][c] = sum_p dout*t.
+//   stage 0: du[n][c] = (|u| < 3) ? A*gamma/6 : 0
+//   stage 1: dgamma[c] = sum_n A*gate ; dbfc[c] = sum_n du
+//   stage 2: dWfc[co][ci] = sum_n du[n][co]*s[n][ci]
+//   stage 3: add[n][ci] = inv_hw * sum_co W[co][ci]*du[n][co]
+__global__ void ese_bwd_kernel(int stage, const float* __restrict__ A, const float* __restrict__ gate, const float* __restrict__ u,
+                               const float* __restrict__ gamma, const float* __restrict__ s, const float* __restrict__ w, int n, int c, float inv_hw,
+                               float* __restrict__ du, float* __restrict__ dgamma, float* __restrict__ dbfc, float* __restrict__ dwfc,
+                               float* __restrict__ add) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (stage == 0) {
+        if (i >= (long)n * c) return;
+        const float uv = u[i];
+        du[i] = (uv > -3.f && uv < 3.f) ? A[i] * gamma[i % c] * (1.f / 6.f) : 0.f;
+    } else if (stage == 1) {
+        if (i >= c) return;
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < n; ++k) {
+            a = fmaf(A[(long)k * c + i], gate ? gate[(long)k * c + i] : 1.f, a);
+            if (du) b += du[(long)k * c + i];
+        }
+        dgamma[i] = a;
+        if (dbfc) dbfc[i] = b;
+    } else if (stage == 2) {
+        if (i >= (long)c * c) return;
+        const int co = i / c, ci = i % c;
+        float a = 0.f;
+        for (int k = 0; k < n; ++k) a = fmaf(du[(long)k * c + co], s[(long)k * c + ci], a);
+        dwfc[i] = a;
+    } else {
+        if (i >= (long)n * c) return;
+        const int img = i / c, ci = i % c;
+        float a = 0.f;
+        for (int co = 0; co < c; ++co) a = fmaf(w[(long)co * c + ci], du[(long)img * c + co], a);
+        add[i] = a * inv_hw;
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                             \
+    do {                                                                    \
+        if ((dtype) == PSSR_BF16) { using T = bf16_t; CALL; }               \
+        else if ((dtype) == PSSR_F32) { using T = float; CALL; }            \
+        else { pssr_set_error("bad dtype %d", (dtype)); return PSSR_ERR_ARG; } \
+    } while (0)
+#define CHECK_REF(name, cs, co, c)                                                                               \
+    PSSR_CHECK((cs) % 4 == 0 && (co) % 4 == 0 && (co) + (c) <= (cs), PSSR_ERR_ARG, name ": bad channel stride/offset (%d,%d,%d)", cs, co, c)
+
+extern "C" {
+
+int pssr_input_patchify(const float* x, void* xpatch, int n, int c, int h, int w, int ps, int pc, float pre_scale, float pre_shift,
+                        const float* scale, const float* shift, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(x && xpatch && scale && shift && n > 0 && c > 0 && ps > 0 && h % ps == 0 && w % ps == 0 && pc >= c * ps * ps && pc % 16 == 0,
+               PSSR_ERR_ARG, "input_patchify: bad args");
+    const long total = (long)n * (h / ps) * (w / ps) * pc;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, x, (T*)xpatch, n, c, h, w, ps, pc,
+                                         pre_scale, pre_shift, scale, shift));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_dwconv7_pack(const float* w, float* packed, int c, int flip, pssr_stream_t s) {
+    PSSR_CHECK(w && packed && c > 0, PSSR_ERR_ARG, "dwconv7_pack: bad args");
+    hipLaunchKernelGGL(dw_pack_kernel, dim3(grid1d(49L * c, 256)), dim3(TPB), 0, (hipStream_t)s, w, packed, c, flip);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, const float* bias, void* out, int out_cs, int out_co,
+                 int n, int h, int w, int c, int accumulate, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(in && w_packed && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7: bad args");
+    CHECK_REF("dwconv7 in", in_cs, in_co, c); CHECK_REF("dwconv7 out", out_cs, out_co, c);
+    const long total = (long)n * h * w * (c / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_kernel<T>, dim3(grid1d(total, 1 << 20)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co}, w_packed, bias,
+                                         MRef{out, out_cs, out_co}, n, h, w, c, accumulate));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h, int w, int c,
+                       int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dy && x && dw && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7_wgrad: bad args");
+    CHECK_REF("dwconv7_wgrad dy", dy_cs, dy_co, c); CHECK_REF("dwconv7_wgrad x", x_cs, x_co, c);
+    const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
+    long gx = ((long)n * h * w + ppb - 1) / ppb / 16;       // >= 16 pixels per thread before the atomics
+    if (gx < 1) gx = 1;
+    if (gx > 96) gx = 96;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_kernel<T>, dim3((unsigned)gx, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
+                                         Ref{x, x_cs, x_co}, dw, n, h, w, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_layernorm2d_fwd(const void* in, int in_cs, int in_co, const float* gamma, const float* beta, float eps, void* out, int out_cs, int out_co,
+                         int s2d, int c_pad, int n, int h, int w, int c, float* mean, float* rstd, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(in && gamma && beta && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && c <= 256 * LN_MAXIT, PSSR_ERR_ARG,
+               "layernorm2d_fwd: bad args (c=%d)", c);
+    PSSR_CHECK(c_pad >= c && c_pad % 4 == 0 && (!s2d || (h % 2 == 0 && w % 2 == 0)), PSSR_ERR_ARG, "layernorm2d_fwd: c_pad / s2d");
+    PSSR_CHECK((mean == nullptr) == (rstd == nullptr), PSSR_ERR_ARG, "layernorm2d_fwd: mean/rstd come in pairs");
+    CHECK_REF("layernorm2d_fwd in", in_cs, in_co, c); CHECK_REF("layernorm2d_fwd out", out_cs, out_co, (s2d ? 4 : 1) * c_pad);
+    const long npix = (long)n * h * w;
+    long blocks = (npix + TPB / 64 - 1) / (TPB / 64);
+    if (blocks > 4096) blocks = 4096;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co}, gamma, beta, eps,
+                                         MRef{out, out_cs, out_co}, s2d, c_pad, npix, h, w, c, mean, rstd));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, const void* x, int x_cs, int x_co, const float* gamma,
+                         const float* mean, const float* rstd, void* dx, int dx_cs, int dx_co, int accumulate, int n, int h, int w, int c,
+                         double* stats, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(g && x && gamma && mean && rstd && dx && stats && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && c <= 256 * LN_MAXIT,
+               PSSR_ERR_ARG, "layernorm2d_bwd: bad args (c=%d)", c);
+    PSSR_CHECK(c_pad >= c && c_pad % 4 == 0 && (!s2d || (h % 2 == 0 && w % 2 == 0)), PSSR_ERR_ARG, "layernorm2d_bwd: c_pad / s2d");
+    CHECK_REF("layernorm2d_bwd g", g_cs, g_co, (s2d ? 4 : 1) * c_pad); CHECK_REF("layernorm2d_bwd x", x_cs, x_co, c); CHECK_REF("layernorm2d_bwd dx", dx_cs, dx_co, c);
+    const long npix = (long)n * h * w;
+    long blocks = (npix + TPB / 64 - 1) / (TPB / 64) / 8;    // >= 8 pixels per wave before the statistics are flushed
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, c_pad,
+                                         Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c, float scale, float* out,
+                           int dtype, pssr_stream_t s) {
+    PSSR_CHECK(a && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "image_channel_dot: bad args");
+    CHECK_REF("image_channel_dot a", a_cs, a_co, c);
+    if (b) CHECK_REF("image_channel_dot b", b_cs, b_co, c);
+    const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
+    int gx = (hw + ppb - 1) / ppb / 8;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(image_channel_dot_kernel<T>, dim3(gx, n), dim3(TPB), 0, (hipStream_t)s, Ref{a, a_cs, a_co}, Ref{b, b_cs, b_co},
+                                         hw, c, scale, out));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_ese_gate(const float* s_mean, const float* w_fc, const float* b_fc, int n, int c, float* u, float* gate, pssr_stream_t s) {
+    PSSR_CHECK(s_mean && w_fc && b_fc && u && gate && n > 0 && c > 0, PSSR_ERR_ARG, "ese_gate: bad args");
+    hipLaunchKernelGGL(ese_gate_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, (hipStream_t)s, s_mean, w_fc, b_fc, n, c, u, gate);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_scale_nc(const void* t, int t_cs, int t_co, const float* gate, const float* gamma, const float* add, void* out, int out_cs, int out_co,
+                  int n, int hw, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(t && gamma && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "scale_nc: bad args");
+    CHECK_REF("scale_nc t", t_cs, t_co, c); CHECK_REF("scale_nc out", out_cs, out_co, c);
+    const long npix = (long)n * hw;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(scale_nc_kernel<T>, dim3(grid1d(npix * (c / 4))), dim3(TPB), 0, (hipStream_t)s, Ref{t, t_cs, t_co}, gate, gamma, add,
+                                         MRef{out, out_cs, out_co}, npix, hw, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float* gamma, const float* s_mean, const float* w_fc, int n, int c, int hw,
+                 float* du, float* dgamma, float* db_fc, float* dw_fc, float* add, pssr_stream_t s) {
+    PSSR_CHECK(A && gamma && dgamma && n > 0 && c > 0 && hw > 0, PSSR_ERR_ARG, "ese_bwd: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const float inv_hw = 1.f / (float)hw;
+    if (gate) {
+        PSSR_CHECK(u && s_mean && w_fc && du && db_fc && dw_fc && add, PSSR_ERR_ARG, "ese_bwd: gate path needs u, s, W, du, db, dW, add");
+        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 0, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, st, 1, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c * c, TPB)), dim3(TPB), 0, st, 2, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 3, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+    } else {
+        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, st, 1, A, (const float*)nullptr, u, gamma, s_mean, w_fc, n, c, inv_hw,
+                           (float*)nullptr, dgamma, (float*)nullptr, dw_fc, add);
+    }
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+}  // extern "C"

@@ -40,8 +40,9 @@ def pack_conv_weight(w: torch.Tensor, dtype: int, mode: int = 0, ci_begin: int =
     assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
     cout, cin, ks, _ = w.shape
     ci_count = cin - ci_begin if ci_count is None else ci_count
-    gk = ci_count if mode == 0 else cout if mode in (1, 3) else ci_count * ks * ks
-    gn = ci_count if mode == 1 else ci_count * ks * ks if mode == 3 else cout
+    s2dk = ks * ks * pad_to(cin, 16)
+    gk = ci_count if mode == 0 else cout if mode in (1, 3, 5) else s2dk if mode == 4 else ci_count * ks * ks
+    gn = ci_count if mode == 1 else ci_count * ks * ks if mode == 3 else s2dk if mode == 5 else cout
     taps = 1 if mode >= 2 else ks * ks
     k_pad, n_pad = pad_to(gk, 16), pad_to(gn, 128)
     if out is None:
@@ -56,7 +57,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
            x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
            pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
            aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None,
-           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0):
+           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False):
     """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff)."""
     d = L.ConvDesc()
     d.dtype = w0.dtype
@@ -65,7 +66,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
     if w1 is not None:
         d.in1, d.in1_cstride, d.in1_coff, d.cin1, d.taps1, d.w1 = L.ptr(x1), x1.shape[-1], in1_coff, cin1, w1.taps, L.ptr(w1.data)
         assert w1.n_pad == w0.n_pad and w1.dtype == w0.dtype
-    d.prologue = L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
+    d.prologue = L.PRO_GELU if gelu_in else L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
     d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
     d.out, d.out_cstride, d.out_coff, d.cout, d.n_pad = L.ptr(out), out.shape[-1], out_coff, cout, w0.n_pad
     d.bias = L.ptr(bias)
@@ -82,14 +83,14 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
 
 
 def conv2d_wgrad(dy, cout, x, cin_pad, taps, dw, *, n, h, w, dtype, dy_coff=0, in_coff=0, dy_blk=0, in_blk=0,
-                 pro_scale=None, pro_shift=None):
+                 pro_scale=None, pro_shift=None, gelu_in=False):
     """dw (f32 [cout, taps, cin_pad], zeroed by the caller) += dy^T (*) prologue(x)."""
     d = L.WgradDesc()
     d.dtype, d.n, d.h, d.w = dtype, n, h, w
     d.dy, d.dy_cstride, d.dy_coff, d.dy_blk, d.cout = L.ptr(dy), dy.shape[-1], dy_coff, dy_blk, cout
     d.in_, d.in_cstride, d.in_coff, d.in_blk, d.cin_pad = L.ptr(x), x.shape[-1], in_coff, in_blk, cin_pad
     d.taps = taps
-    d.prologue = L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
+    d.prologue = L.PRO_GELU if gelu_in else L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
     d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
     d.dw = L.ptr(dw)
     L.check(L.lib().pssr_conv2d_wgrad(C.byref(d), L.stream_ptr()), "pssr_conv2d_wgrad")
@@ -288,3 +289,72 @@ def adamw_step_dev(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scal
     L.check(L.lib().pssr_adamw_step_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), L.ptr(state), C.c_float(beta1),
                                         C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_float(grad_scale),
                                         L.stream_ptr()), "pssr_adamw_step_dev")
+
+
+# ----------------------------------------------------------------------------------------------
+# RDNet encoder kernels (csrc/rdnet.hip)
+def input_patchify(x, xpatch, scale, shift, patch, dtype, pre_scale=1 / 128, pre_shift=-1.0):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_input_patchify(L.ptr(x), L.ptr(xpatch), n, c, h, w, patch, xpatch.shape[-1], C.c_float(pre_scale),
+                                        C.c_float(pre_shift), L.ptr(scale), L.ptr(shift), dtype, L.stream_ptr()), "pssr_input_patchify")
+
+
+def input_norm_bwd2(dxcol_a, dxcol_b, dpatch, patch, x, mean, invstd, stats, dtype, pre_scale=1 / 128, pre_shift=-1.0):
+    n, c, h, w = x.shape
+    col = dxcol_a if dxcol_a is not None else dxcol_b
+    L.check(L.lib().pssr_input_norm_bwd2(L.ptr(dxcol_a), L.ptr(dxcol_b), col.shape[-1] if col is not None else 0, L.ptr(dpatch),
+                                         dpatch.shape[-1] if dpatch is not None else 0, patch, L.ptr(x), C.c_float(pre_scale),
+                                         C.c_float(pre_shift), L.ptr(mean), L.ptr(invstd), n, c, h, w, L.ptr(stats), dtype,
+                                         L.stream_ptr()), "pssr_input_norm_bwd2")
+
+
+def dwconv7_pack(w, out, flip=False):
+    """torch depthwise weight [C,1,7,7] f32 -> [49][C] f32 (flip: rotated 180 degrees for the input gradient)."""
+    c = w.shape[0]
+    L.check(L.lib().pssr_dwconv7_pack(L.ptr(w), L.ptr(out), c, int(flip), L.stream_ptr()), "pssr_dwconv7_pack")
+    return out
+
+
+def dwconv7(x, wp, bias, out, n, h, w, c, dtype, in_coff=0, out_coff=0, accumulate=False):
+    L.check(L.lib().pssr_dwconv7(*_ref(x, in_coff), L.ptr(wp), L.ptr(bias), *_ref(out, out_coff), n, h, w, c, int(accumulate), dtype,
+                                 L.stream_ptr()), "pssr_dwconv7")
+
+
+def dwconv7_wgrad(dy, x, dw, n, h, w, c, dtype, dy_coff=0, x_coff=0):
+    L.check(L.lib().pssr_dwconv7_wgrad(*_ref(dy, dy_coff), *_ref(x, x_coff), L.ptr(dw), n, h, w, c, dtype, L.stream_ptr()), "pssr_dwconv7_wgrad")
+
+
+def layernorm2d_fwd(x, gamma, beta, eps, out, n, h, w, c, dtype, in_coff=0, out_coff=0, s2d=False, c_pad=None, mean=None, rstd=None):
+    c_pad = pad_to(c, 16) if c_pad is None else c_pad
+    L.check(L.lib().pssr_layernorm2d_fwd(*_ref(x, in_coff), L.ptr(gamma), L.ptr(beta), C.c_float(eps), *_ref(out, out_coff), int(s2d), c_pad,
+                                         n, h, w, c, L.ptr(mean), L.ptr(rstd), dtype, L.stream_ptr()), "pssr_layernorm2d_fwd")
+
+
+def layernorm2d_bwd(g, x, gamma, mean, rstd, dx, stats, n, h, w, c, dtype, g_coff=0, x_coff=0, dx_coff=0, s2d=False, c_pad=None,
+                    accumulate=False):
+    c_pad = pad_to(c, 16) if c_pad is None else c_pad
+    L.check(L.lib().pssr_layernorm2d_bwd(*_ref(g, g_coff), int(s2d), c_pad, *_ref(x, x_coff), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                         *_ref(dx, dx_coff), int(accumulate), n, h, w, c, L.ptr(stats), dtype, L.stream_ptr()),
+            "pssr_layernorm2d_bwd")
+
+
+def image_channel_dot(a, b, n, hw, c, scale, out, dtype, a_coff=0, b_coff=0):
+    bref = _ref(b, b_coff) if b is not None else (None, 0, 0)
+    L.check(L.lib().pssr_image_channel_dot(*_ref(a, a_coff), *bref, n, hw, c, C.c_float(scale), L.ptr(out), dtype, L.stream_ptr()),
+            "pssr_image_channel_dot")
+
+
+def ese_gate(s_mean, w_fc, b_fc, u, gate):
+    n, c = s_mean.shape
+    L.check(L.lib().pssr_ese_gate(L.ptr(s_mean), L.ptr(w_fc), L.ptr(b_fc), n, c, L.ptr(u), L.ptr(gate), L.stream_ptr()), "pssr_ese_gate")
+
+
+def scale_nc(t, gate, gamma, add, out, n, hw, c, dtype, t_coff=0, out_coff=0):
+    L.check(L.lib().pssr_scale_nc(*_ref(t, t_coff), L.ptr(gate), L.ptr(gamma), L.ptr(add), *_ref(out, out_coff), n, hw, c, dtype,
+                                  L.stream_ptr()), "pssr_scale_nc")
+
+
+def ese_bwd(A, gate, u, gamma, s_mean, w_fc, hw, du, dgamma, db_fc, dw_fc, add):
+    n, c = A.shape
+    L.check(L.lib().pssr_ese_bwd(L.ptr(A), L.ptr(gate), L.ptr(u), L.ptr(gamma), L.ptr(s_mean), L.ptr(w_fc), n, c, hw, L.ptr(du),
+                                 L.ptr(dgamma), L.ptr(db_fc), L.ptr(dw_fc), L.ptr(add), L.stream_ptr()), "pssr_ese_bwd")
