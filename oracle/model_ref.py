@@ -40,7 +40,18 @@ def _rec(record, name, t):
     return t
 
 
-def resblock_forward(x, sd, prefix, depth, train, new_stats, record=None):
+def _relu(h, name, masks, record):
+    """ReLU.  ``masks`` (test instrumentation): {name: 0/1 tensor} replaces the sign decision by a given mask, so that a
+    gradient check can be made independent of ReLU inputs that lie within round-off of zero; ``record`` keeps the
+    pre-activation under name + ".pre"."""
+    if record is not None:
+        record[name + ".pre"] = h.detach()
+    if masks is not None and name in masks:
+        return h * masks[name].to(h.dtype)
+    return F.relu(h)
+
+
+def resblock_forward(x, sd, prefix, depth, train, new_stats, record=None, masks=None):
     """pssr/models/_blocks.py:39-41 with the Sequential laid out as at :26-33."""
     n_layers = max(depth, 0) + 1
     h = x
@@ -48,19 +59,20 @@ def resblock_forward(x, sd, prefix, depth, train, new_stats, record=None):
         h = _rec(record, f"{prefix}.y{i}", F.conv2d(h, sd[f"{prefix}.conv.{3 * i}.weight"], sd[f"{prefix}.conv.{3 * i}.bias"], padding=1))
         h = _bn(h, sd, f"{prefix}.conv.{3 * i + 1}", train, new_stats)
         if i + 1 < n_layers:
-            h = F.relu(h)
+            h = _relu(h, f"{prefix}.relu{i}", masks, record)
     r = F.conv2d(x, sd[f"{prefix}.respass.weight"], sd[f"{prefix}.respass.bias"])
-    return _rec(record, f"{prefix}.out", F.relu(h + r))
+    return _rec(record, f"{prefix}.out", _relu(h + r, f"{prefix}.tail", masks, record))
 
 
-def reconstruction_forward(x, sd, prefix, scale, record=None):
+def reconstruction_forward(x, sd, prefix, scale, record=None, masks=None):
     """pssr/models/_blocks.py:15-18."""
-    x = _rec(record, f"{prefix}.pre_out", F.relu(F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1)))
+    x = F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1)
+    x = _rec(record, f"{prefix}.pre_out", _relu(x, f"{prefix}.pre", masks, record))
     x = F.pixel_shuffle(x, scale)
     return F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], padding=1)
 
 
-def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None):
+def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None, masks=None):
     """ResUNet.forward (pssr/models/resunet.py:65-96), non-atrous, no PSP pooling.
 
     ``x``: float32 [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats).
@@ -70,7 +82,7 @@ def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None)
     x = _bn(x, sd, "norm", train, new_stats)
     skips = [x]
     for i in range(n_levels):
-        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats, record)
+        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats, record, masks)
         if i + 1 < n_levels:
             skips.append(x)
             x = F.max_pool2d(x, kernel_size=2)
@@ -78,10 +90,10 @@ def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None)
         x = F.pixel_shuffle(x, 2)
         x = torch.cat([x, skips.pop()], dim=1)
         x = _rec(record, f"decoder.{j}.in", x)
-        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats, record)
+        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats, record, masks)
     x = torch.cat([x, skips.pop()], dim=1)
     assert not skips
-    x = reconstruction_forward(x, sd, "reconstruction", scale, record)
+    x = reconstruction_forward(x, sd, "reconstruction", scale, record, masks)
     return x * 128 + 128, new_stats
 
 

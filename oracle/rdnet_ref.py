@@ -112,7 +112,7 @@ def rdnet_forward(x, sd, cfg: RDConfig, prefix="encoder", record=None):
     return (*skips, x)
 
 
-def rdresunet_forward(x, sd, cfg: RDConfig, train=False, record=None):
+def rdresunet_forward(x, sd, cfg: RDConfig, train=False, record=None, masks=None):
     """RDResUNet.forward (pssr/models/rdresunet.py:104-130), non-atrous, no PSP pooling.
     ``x``: float [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats)."""
     new_stats: dict[str, torch.Tensor] = {}
@@ -123,11 +123,11 @@ def rdresunet_forward(x, sd, cfg: RDConfig, train=False, record=None):
     for k in range(len(cfg.hidden)):
         x = torch.cat([x, skips.pop()], dim=1) if k else skips.pop()
         x = _rec(record, f"decoder.{k}.in", x)
-        x = resblock_forward(x, sd, f"decoder.{k}", cfg.depth, train, new_stats, record)
+        x = resblock_forward(x, sd, f"decoder.{k}", cfg.depth, train, new_stats, record, masks)
         x = F.pixel_shuffle(x, cfg.ratios[k + 1])
     x = torch.cat([x, skips.pop()], dim=1)
     assert not skips
-    x = reconstruction_forward(x, sd, "reconstruction", cfg.scale, record)
+    x = reconstruction_forward(x, sd, "reconstruction", cfg.scale, record, masks)
     return x * 128 + 128, new_stats
 
 

@@ -9,6 +9,9 @@ def __getattr__(name):
     if name in ("ResUNet",):
         from .models import ResUNet
         return ResUNet
+    if name in ("RDResUNet",):
+        from .models import RDResUNet
+        return RDResUNet
     if name in ("SSIMLoss",):
         from .util import SSIMLoss
         return SSIMLoss

@@ -50,7 +50,7 @@ class ResBlock(nn.Module):
         self.depth = depth
 
 
-class _ResUNetFunction(torch.autograd.Function):
+class _EngineFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are engine kernel sequences."""
 
     @staticmethod
@@ -112,8 +112,182 @@ class ResUNet(nn.Module):
 
     def forward(self, x):
         params = [p for p in self.parameters()]
-        return _ResUNetFunction.apply(self._engine, x, *params)
+        return _EngineFunction.apply(self._engine, x, *params)
 
     def extra_repr(self):
         return (f"ResUNet with {self.reconstruction.scale}x upscaling\n{len(self.encoder)} residual decoder blocks with "
                 f"{self.encoder[0].depth} hidden layers each\nPSP pooling disabled")
+
+
+# ------------------------------------------------------------------------------------------------
+# RDResUNet: RDNet (Revitalized DenseNet) encoder + ResUNet decoder (pssr/models/rdresunet.py, pssr/models/_rdnet.py)
+class _LayerNorm2d(nn.LayerNorm):
+    """Parameter container of timm's LayerNorm2d (weight / bias of shape (C,), eps 1e-6)."""
+
+    def __init__(self, num_channels, eps=1e-6):
+        super().__init__(num_channels, eps=eps)
+
+
+class _EffectiveSE(nn.Module):
+    """Parameter container of timm's EffectiveSEModule: ``fc`` = Conv2d(C, C, 1)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.fc = nn.Conv2d(channels, channels, kernel_size=1, padding=0)
+
+
+class _Block(nn.Module):
+    """dw7x7 -> LayerNorm2d -> 1x1 -> GELU -> 1x1 [-> ESE] (pssr/models/_rdnet.py:177-206)."""
+
+    def __init__(self, in_chs, inter_chs, out_chs, ese):
+        super().__init__()
+        layers = [nn.Conv2d(in_chs, in_chs, groups=in_chs, kernel_size=7, stride=1, padding=3), _LayerNorm2d(in_chs, eps=1e-6),
+                  nn.Conv2d(in_chs, inter_chs, kernel_size=1), nn.GELU(), nn.Conv2d(inter_chs, out_chs, kernel_size=1)]
+        if ese:
+            layers.append(_EffectiveSE(out_chs))
+        self.layers = nn.Sequential(*layers)
+
+
+class _DenseBlock(nn.Module):
+    """pssr/models/_rdnet.py:140-175 (gamma is created before the layers; drop_path is a no-op upstream)."""
+
+    def __init__(self, num_input_features, growth_rate, bottleneck_width_ratio, ese, ls_init_value=1e-6):
+        super().__init__()
+        self.growth_rate = growth_rate
+        self.gamma = nn.Parameter(ls_init_value * torch.ones(growth_rate))
+        inter_chs = int(num_input_features * bottleneck_width_ratio / 8) * 8
+        self.drop_path = nn.Identity()
+        self.layers = _Block(num_input_features, inter_chs, int(growth_rate), ese)
+
+
+class _DenseStage(nn.Sequential):
+    def __init__(self, num_block, num_input_features, growth_rate, bottleneck_width_ratio, ese):
+        super().__init__()
+        for i in range(num_block):
+            self.add_module(f"dense_block{i}", _DenseBlock(num_input_features, growth_rate, bottleneck_width_ratio, ese))
+            num_input_features += growth_rate
+        self.num_out_features = num_input_features
+
+
+class _PatchifyStem(nn.Module):
+    def __init__(self, num_input_channels, num_init_features, patch_size):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(num_input_channels, num_init_features, kernel_size=patch_size, stride=patch_size),
+                                  _LayerNorm2d(num_init_features))
+
+
+def _kaiming_all_convs(module):
+    """timm.models.named_apply(_init_weights) of the reference (pssr/models/_rdnet.py:91,208-213): depth-first, children
+    before the module, kaiming_normal_ on every Conv2d weight (BatchNorm2d: weight 1, bias 0)."""
+    for child in module.children():
+        _kaiming_all_convs(child)
+        if isinstance(child, nn.Conv2d):
+            nn.init.kaiming_normal_(child.weight)
+        elif isinstance(child, nn.BatchNorm2d):
+            nn.init.constant_(child.weight, 1), nn.init.constant_(child.bias, 0)
+
+
+class RDNet(nn.Module):
+    """Parameter tree of the reference's RDNet (pssr/models/_rdnet.py:15-93); executed by pssr2_amd.rd_engine."""
+
+    def __init__(self, in_channels=1, n_init_features=128, patch_size=2, growth_rates=(64, 104, 128, 128, 128, 128, 224),
+                 ds_blocks=(False, True, True, False, False, False, True),
+                 block_type=("Block", "Block", "BlockESE", "BlockESE", "BlockESE", "BlockESE", "BlockESE"), n_blocks=(3, 3, 3, 3, 3, 3, 3),
+                 bottleneck_width_ratio=4, drop_path_rate=0.0, transition_compression_ratio=0.5, ls_init_value=1e-6):
+        super().__init__()
+        growth_rates = list(growth_rates)
+        block_type = [block_type] * len(growth_rates) if type(block_type) is str else list(block_type)
+        ese = [bool(b) and b != "Block" for b in block_type]      # upstream: truthy entries (bools from RDResUNet) become BlockESE
+        n_blocks = [n_blocks] * len(growth_rates) if type(n_blocks) is int else list(n_blocks)
+        if not len(growth_rates) == len(ds_blocks):
+            raise ValueError(f"growth_rates and ds_blocks must have the same length. Given values are {len(growth_rates)} and {len(ds_blocks)} respectively.")
+        if not len(growth_rates) == len(block_type):
+            raise ValueError(f"growth_rates and block_type must have the same length. Given values are {len(growth_rates)} and {len(block_type)} respectively.")
+        if not len(growth_rates) == len(n_blocks):
+            raise ValueError(f"growth_rates and n_blocks must have the same length. Given values are {len(growth_rates)} and {len(n_blocks)} respectively.")
+        self.stem = _PatchifyStem(in_channels, n_init_features, patch_size=patch_size)
+        self.feature_info = []
+        self.num_stages = len(growth_rates)
+        curr_stride = 4
+        num_features = n_init_features
+        dense_stages = []
+        self.stage_in, self.stage_out, self.trans_in = [], [], []
+        for i in range(self.num_stages):
+            layers = []
+            self.trans_in.append(num_features if i else 0)
+            if i != 0:
+                compressed = int(num_features * transition_compression_ratio / 8) * 8
+                k_size = stride = 1
+                if ds_blocks[i]:
+                    curr_stride *= 2
+                    k_size = stride = 2
+                layers.append(_LayerNorm2d(num_features))
+                layers.append(nn.Conv2d(num_features, compressed, kernel_size=k_size, stride=stride, padding=0))
+                num_features = compressed
+            self.stage_in.append(num_features)
+            layers.append(_DenseStage(n_blocks[i], num_features, growth_rates[i], bottleneck_width_ratio, ese[i]))
+            num_features += n_blocks[i] * growth_rates[i]
+            self.stage_out.append(num_features)
+            if i + 1 == self.num_stages or ds_blocks[i + 1]:
+                self.feature_info += [dict(num_chs=num_features, reduction=curr_stride, module=f"dense_stages.{i}", growth_rate=growth_rates[i])]
+            dense_stages.append(nn.Sequential(*layers))
+        self.dense_stages = nn.ModuleList(dense_stages)
+        _kaiming_all_convs(self)
+        self.ds_blocks, self.ese_blocks, self.n_blocks, self.growth_rates = list(ds_blocks), ese, n_blocks, growth_rates
+        self.patch_size, self.n_init_features = patch_size, n_init_features
+
+
+class RDResUNet(nn.Module):
+    def __init__(self, channels=1, hidden=[1024, 1024, 512, 256], scale: int = 4, depth: int = 3, dilations=None, pool_sizes=None,
+                 encoder_pool: bool = False, rdnet_init: int = 128, growth_rates=[64, 104, 128, 128, 128, 128, 224],
+                 ds_blocks=[False, True, True, False, False, False, True], ese_blocks=[False, False, True, True, True, True, True],
+                 n_blocks=[3, 3, 3, 3, 3, 3, 3], patch_size: int = 2, bottleneck: int = 4, compression: float = 0.5, drop_rate: float = 0):
+        r"""RDNet (Revitalized DenseNet) encoder + ResUNet decoder + upscaling head; same arguments, module tree and
+        ``state_dict`` as the reference (pssr/models/rdresunet.py:9-102).  ``dilations`` / ``pool_sizes`` are validated like
+        the reference but not implemented on the MI355X path; ``drop_rate`` is a no-op upstream too (_rdnet.py:161,168-175).
+
+        Extra attribute: ``compute_dtype`` (torch.float32 — exact-f32 MFMA — or torch.bfloat16).
+        """
+        super().__init__()
+        channels = _force_list(channels)
+        channels = channels * 2 if len(channels) == 1 else channels
+        hidden = list(hidden)
+        if dilations and len(dilations) != len(hidden):
+            raise ValueError(f"Amount of dilations must equal amount of hidden residual blocks. Given values are {len(dilations)} and {len(hidden)} respectively.")
+        if pool_sizes:
+            if hidden[0] % len(pool_sizes) != 0:
+                raise ValueError(f"hidden[0] must be divisible by len(pool_sizes). Given values are {hidden[0]} and {len(pool_sizes)} respectively.")
+            if encoder_pool and hidden[-1] % len(pool_sizes) != 0:
+                raise ValueError(f"hidden[-1] must be divisible by len(pool_sizes) if encoder_pool is True. Given values are {hidden[-1]} and {len(pool_sizes)} respectively.")
+        elif encoder_pool:
+            raise ValueError("encoder_pool cannot be True if pool_sizes are not provided.")
+        if dilations or pool_sizes:
+            raise NotImplementedError("atrous / PSP-pooling RDResUNet variants are not implemented on the MI355X path yet")
+        self.norm = nn.BatchNorm2d(channels[0])
+        if sum(ds_blocks) != len(hidden) - 1:
+            raise ValueError(f"Number of downsampling blocks must be one less than ResUNet hidden layers. Given {sum(ds_blocks)} downsampling blocks but {len(hidden)} hidden layers.")
+        # positional order as upstream (rdresunet.py:84): ese_blocks lands in block_type, drop_rate in drop_path_rate
+        self.encoder = RDNet(channels[0], rdnet_init, patch_size, growth_rates, ds_blocks, ese_blocks, n_blocks, bottleneck, drop_rate, compression)
+        skips = [feature["num_chs"] for feature in self.encoder.feature_info]
+        skips.reverse()
+        if len(skips) != len(hidden):
+            raise ValueError(f"Each encoder skip connection must have a corresponding decoder hidden layer. There are {len(skips)} skip connections but {len(hidden)} hidden layers.")
+        self.ratios = [1] + [2] * (len(skips) - 1) + [patch_size]
+        layers = [0, *hidden]
+        self.decoder = nn.ModuleList()
+        for k in range(len(layers) - 1):
+            self.decoder.append(ResBlock(layers[k] // self.ratios[k] ** 2 + skips[k], layers[k + 1], depth))
+        self.reconstruction = Reconstruction(channels[0], channels[1], hidden[-1] // self.ratios[-1] ** 2, scale)
+        self.skips = skips
+        self.channels, self.hidden, self.depth = channels, hidden, depth
+        self.compute_dtype = torch.float32
+        from .rd_engine import RDEngine
+        self._engine = RDEngine(self)
+
+    def forward(self, x):
+        params = [p for p in self.parameters()]
+        return _EngineFunction.apply(self._engine, x, *params)
+
+    def extra_repr(self):
+        return (f"RDResUNet with {self.reconstruction.scale}x upscaling\n{len(self.decoder)} residual blocks with "
+                f"{self.decoder[0].depth} hidden layers each\nSkip connection sizes: {self.skips}\nPSP pooling disabled")

@@ -148,3 +148,30 @@ def test_array_dataset_protocol():
     assert lr_ds.is_lr and lr_ds[0].shape == (1, 64, 64) and len(lr_ds.val_idx) == 5
     sl = SlidingArrayDataset([np.zeros((1, 100, 90), np.uint8)], hr_res=32, overlap=8)
     assert len(sl) == 9 and sl._get_name(4) == "sheet0_4_0" and sl[8].shape == (1, 32, 32)
+
+
+def test_rdresunet_tree_and_init_match_reference(golden):
+    """RDResUNet: state_dict keys / shapes / parameter count and, under the same torch seed, the same initial weights as the
+    reference (creation order + the kaiming_normal_ pass of RDNet, pssr/models/_rdnet.py:91,208-213); constructor errors."""
+    import torch
+    from pssr2_amd.models import RDResUNet
+    g = golden("rdmodel.npz")
+    torch.manual_seed(1234)
+    m = RDResUNet()
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["default_keys"].tolist()
+    assert [str(tuple(v.shape)) for v in sd.values()] == g["default_shapes"].tolist()
+    assert sum(p.numel() for p in m.parameters()) == int(g["default_nparams"]) == 115744923
+    assert m.skips == g["default_skips"].tolist() and m.extra_repr() == str(g["default_repr"])
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    np.testing.assert_allclose(sums, g["default_sums"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.array([float(v.double().abs().sum()) for v in sd.values()]), g["default_abssums"], rtol=1e-9, atol=1e-9)
+    with pytest.raises(ValueError, match="downsampling blocks"):
+        RDResUNet(hidden=[64, 64])
+    with pytest.raises(ValueError, match="same length"):
+        RDResUNet(growth_rates=[8, 8])      # 2 growth rates vs 7 ds_blocks (3 of them True, matching 4 hidden layers)
+    with pytest.raises(ValueError, match="encoder_pool"):
+        RDResUNet(encoder_pool=True)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        RDResUNet(hidden=[32, 32], rdnet_init=16, growth_rates=[8, 8, 16], ds_blocks=[False, False, True], ese_blocks=[True, False, True],
+                  n_blocks=[1, 2, 1])(torch.zeros(1, 1, 32, 32))
