@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--lr-res", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--model", default="resunet", choices=["resunet", "rdresunet"],
+                    help="resunet = BASELINE.json configs[1] (default, the metric's config); rdresunet = configs[2] (RDNet encoder)")
+    ap.add_argument("--crappifier", default="gaussian", choices=["gaussian", "poisson"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     args = ap.parse_args()
@@ -126,15 +129,15 @@ def main():
     torch.cuda.set_device(local if world > 1 else 0)
     dev = torch.device("cuda", local if world > 1 else 0)
 
-    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.crappifiers import AdditiveGaussian, Poisson
     from pssr2_amd.data import DevicePairGenerator, synthetic_em_tile
-    from pssr2_amd.models import ResUNet
+    from pssr2_amd.models import RDResUNet, ResUNet
     from pssr2_amd.optim import FusedAdamW
     from pssr2_amd.util import SSIMLoss
     import numpy as np
 
     torch.manual_seed(0)
-    model = ResUNet().to(dev)
+    model = (ResUNet() if args.model == "resunet" else RDResUNet()).to(dev)
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     D.broadcast_module(model)
     opt = FusedAdamW(model.parameters(), lr=1e-3)
@@ -151,7 +154,8 @@ def main():
     tile_counter = torch.full((1,), rank * 10 ** 9, dtype=torch.int64, device=dev)
     step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     ar = torch.arange(args.batch, device=dev)
-    gen = DevicePairGenerator(4, AdditiveGaussian(13, 0, 0), seed=1234, tile_counter=tile_counter)
+    crap = AdditiveGaussian(13, 0, 0) if args.crappifier == "gaussian" else Poisson()
+    gen = DevicePairGenerator(4, crap, seed=1234, tile_counter=tile_counter)
     opt.device_state = True
 
     def next_batch():
@@ -273,20 +277,22 @@ def main():
         conv = timer.summary()
         tiles_per_s = world * args.batch * args.steps / elapsed
         gflop_tile = TRAIN_GFLOP_PER_TILE if args.mode == "train" else FWD_GFLOP_PER_TILE
+        if args.model == "rdresunet":      # 53.575 GMAC fwd per tile
+            gflop_tile = 321.45 if args.mode == "train" else 107.15
         scale = (args.lr_res / 128) ** 2
         res = {
             "metric": f"HR tiles/sec (512^2 4xSR) {args.mode}",
             "value": round(tiles_per_s, 2), "unit": "HR tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ResUNet 1-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
-                                   f"AdditiveGaussian(13) device crappifier, MS-SSIM+L1 (mix .8), AdamW",
+            "config": {"workload": f"{'ResUNet' if args.model == 'resunet' else 'RDResUNet'} 1-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
+                                   f"{'AdditiveGaussian(13)' if args.crappifier == 'gaussian' else 'Poisson()'} device crappifier, MS-SSIM+L1 (mix .8), AdamW",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "step_compute": {"algorithmic_tflops": round(tiles_per_s * gflop_tile * scale / 1e3 / world, 2),
                              "frac_of_bf16_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / PEAK_BF16_TFLOPS, 4)},
         }
-        traffic, traffic_src = pmc_traffic(args.mode)
+        traffic, traffic_src = pmc_traffic(args.mode if args.model == 'resunet' else f'{args.model}_{args.mode}')
         if conv:
             res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile,9 taps> (3x3 conv fwd+dgrad, Cout>64)",
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -294,7 +300,7 @@ def main():
                                "traffic_source": traffic_src,
                                "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1), "measured_in": measured_in,
                                "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == "resunet":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:

@@ -6,7 +6,7 @@ small, committed summaries under profiles/:
   profiles/<tag>_<mode>_eager_kernel_stats.csv   same, eager launches
   profiles/<tag>_<mode>_pmc_traffic.csv          per kernel: launches, FETCH_SIZE / WRITE_SIZE per launch (raw, KiB) and
                                                  the corrected HBM bytes per launch
-  profiles/traffic.json                          {mode: {kernel name: bytes per launch}} read by bench.py
+  profiles/traffic.json                          {mode (or model_mode): {kernel name: bytes per launch}} read by bench.py
 
 HBM-byte correction (MI355X_MICROARCH.md, "HBM"): on gfx950 FETCH_SIZE reports half of the bytes of a wide
 coalesced streaming read, WRITE_SIZE is exact; both are in KiB.  traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
