@@ -62,6 +62,10 @@ int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int dtype);
 int pssr_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int cout, int cin, int ks,
                            int ci_begin, int ci_count, int mode, const int32_t* n_perm,
                            int k_pad, int accumulate, pssr_stream_t stream);
+/* same, summing `parts` partial slabs laid out [parts][rows][taps][k_pad] (rows = the wgrad's cout) first */
+int pssr_unpack_conv_wgrad_parts(const float* dw_parts, int parts, int rows, float* dw_oihw, int cout, int cin, int ks,
+                                 int ci_begin, int ci_count, int mode, const int32_t* n_perm,
+                                 int k_pad, int accumulate, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, stride 1, "same" zero padding, NHWC, MFMA 32x32 tiles.
@@ -119,8 +123,11 @@ typedef struct pssr_conv_desc {
 int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d.weight):
- *   dw[n][tap][k] += sum_pixels dy[p][n] * prologue(in)[p + tap][k]      (f32, atomically added;
- * the caller zeroes `dw`, then scatters it to OIHW with pssr_unpack_conv_wgrad).                */
+ *   dw[n][tap][k] = sum_pixels dy[p][n] * prologue(in)[p + tap][k]      (f32)
+ * The pixel reduction is split over workgroups.  dw_parts > 0 (preferred): the caller provides
+ * dw[dw_parts][cout][taps][cin_pad] (no initialisation needed), dw_parts = pssr_conv2d_wgrad_parts(desc); every
+ * workgroup stores its partial slab once and pssr_unpack_conv_wgrad_parts sums the parts while scattering to OIHW.
+ * dw_parts == 0: one caller-zeroed slab, partial sums combined with f32 atomics, then pssr_unpack_conv_wgrad.   */
 typedef struct pssr_wgrad_desc {
     int32_t dtype;
     int32_t n, h, w;
@@ -128,10 +135,13 @@ typedef struct pssr_wgrad_desc {
     const void* in; int32_t in_cstride, in_coff, in_blk, cin_pad; /* cin_pad % 16 == 0            */
     int32_t taps;
     int32_t prologue; const float* pro_scale; const float* pro_shift;
-    float* dw;                                                   /* [cout][taps][cin_pad]        */
+    float* dw;                                                   /* [max(dw_parts,1)][cout][taps][cin_pad] */
+    int32_t dw_parts;
 } pssr_wgrad_desc;
 
 int pssr_conv2d_wgrad(const pssr_wgrad_desc* desc, pssr_stream_t stream);
+/* number of partial slabs this shape is split into (> 0), or a negative PSSR_ERR_*; pointers in `desc` are ignored */
+int pssr_conv2d_wgrad_parts(const pssr_wgrad_desc* desc);
 
 
 /* ---------------------------------------------------------------------------------------------

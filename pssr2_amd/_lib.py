@@ -48,7 +48,7 @@ class WgradDesc(C.Structure):
         ("in_", c_void_p), ("in_cstride", C.c_int32), ("in_coff", C.c_int32), ("in_blk", C.c_int32), ("cin_pad", C.c_int32),
         ("taps", C.c_int32),
         ("prologue", C.c_int32), ("pro_scale", c_void_p), ("pro_shift", c_void_p),
-        ("dw", c_void_p),
+        ("dw", c_void_p), ("dw_parts", C.c_int32),
     ]
 
 

@@ -8,6 +8,8 @@
 // keeps all of it in accumulators (9 tiles per wave), and walks a strided subset of the pixel
 // tiles; per tile it stages dy (128 px) and the input halo tile once and reuses the halo for the 9
 // taps.  Partial slabs are combined with f32 atomics (one add per element per workgroup).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -19,8 +21,9 @@ struct WgradArgs {
     const void* in; int in_cs, in_co, in_blk, cin_pad;     // columns of dW (k), multiple of 16
     int taps;
     int prologue; const float* pro_scale; const float* pro_shift;
-    float* dw;                                             // [cout][taps][cin_pad] f32, atomically accumulated
+    float* dw;                                             // [parts][cout][taps][cin_pad] f32 (parts == 0: one slab, atomics)
     int co_tiles, ci_tiles;
+    int parts; long part_stride;
 };
 
 template <int GEO> struct WGeo;
@@ -44,7 +47,7 @@ template <> struct Frag<bf16_t> {
 };
 
 template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && GEO < 2) ? 2 : 1) void conv_wgrad_kernel(const WgradArgs p) {
     using X = TT<T>;
     constexpr int EPS = X::EPS;
     constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
@@ -54,9 +57,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int PPS = ROWB / 16;                        // 16-byte pieces per sub-tile row
     constexpr int CO_S = CO_T / 32, CI_S = CI_T / 32;     // 32-channel sub-tiles
     static_assert(CO_S * CI_S == 4, "one (cout sub, cin sub) pair per wave");
-    constexpr int DY_BYTES = CO_S * 128 * ROWB, AH_BYTES = CI_S * HP * ROWB;
+    constexpr int DY_BYTES = CO_S * 128 * ROWB;
     constexpr int DY_PIECES = 128 * CO_S * PPS, AH_PIECES = HP * CI_S * PPS;
+    constexpr int DY_ITEMS = (DY_PIECES + 255) / 256, AH_ITEMS = (AH_PIECES + 255) / 256;
     constexpr int KP = (sizeof(T) == 2) ? 16 : 8;         // pixels per k-step
+    // bf16: the loads of pixel tile i+1 are in flight (in registers) while tile i is multiplied; the exact-f32 build
+    // (twice the staging registers) loads synchronously
+    constexpr bool PREFETCH = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Dy = smem;
     char* Ah = smem + DY_BYTES;
@@ -77,63 +84,95 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     const char* dy_img = Dy + cosub * 128 * ROWB;
     const char* ah_img = Ah + cisub * HP * ROWB;
 
-    for (int tile = blockIdx.x; tile < p.n_tiles; tile += p.split) {
-        int tmi = tile;
-        const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
-        const int tile_y = tmi % p.tiles_y;
-        const int tile_i = tmi / p.tiles_y;
-        const int x0 = tile_x << TWL, y0 = tile_y << THL, img0 = tile_i * NI;
+    u32x4 dy_reg[DY_ITEMS], ah_reg[AH_ITEMS];
+    unsigned long long dy_ok = 0, ah_ok = 0;      // validity bits of the staged items (out-of-range items load pixel 0 and are zeroed at commit)
 
-        // ---- stage dy tile: [cout sub][pixel m][32 ch]
-        for (int idx = tid; idx < DY_PIECES; idx += 256) {
-            const int m = idx / (CO_S * PPS), pc = idx % (CO_S * PPS);
-            const int sub = pc / PPS, pin = pc % PPS;
-            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
-            const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
-            const int ch = n0 + pc * EPS;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gi < p.N && gy < p.H && gx < p.W && ch < p.cout)
-                v = *(const u32x4*)(dyp + pix_index(gi, gy, gx, p.H, p.W, p.dy_blk) * p.dy_cs + p.dy_co + ch);
-            *(u32x4*)(Dy + sub * 128 * ROWB + m * ROWB + pin * 16) = v;
-        }
-        // ---- stage input halo tile: [cin sub][halo pixel][32 ch], BN+ReLU applied in flight
-        for (int idx = tid; idx < AH_PIECES; idx += 256) {
-            const int pp = idx / (CI_S * PPS), pc = idx % (CI_S * PPS);
-            const int sub = pc / PPS, pin = pc % PPS;
-            const int img = pp / HPI, rem = pp % HPI;
-            const int hy = rem / HW2, hx = rem % HW2;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
-            const int ch = k0 + pc * EPS;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ch < p.cin_pad) {
-                v = *(const u32x4*)(inp + pix_index(gi, gy, gx, p.H, p.W, p.in_blk) * p.in_cs + p.in_co + ch);
-                if (p.prologue == PSSR_PRO_BN_RELU) {
-                    float f[EPS];
-                    X::unpack(v, f);
-#pragma unroll
-                    for (int e = 0; e < EPS; e += 4) {
-                        const float4 sc = *(const float4*)(p.pro_scale + ch + e);
-                        const float4 sh = *(const float4*)(p.pro_shift + ch + e);
-                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);
-                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);
-                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);
-                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);
-                    }
-                    v = X::pack(f);
-                } else if (p.prologue == PSSR_PRO_GELU) {
-                    float f[EPS];
-                    X::unpack(v, f);
-#pragma unroll
-                    for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);
-                    v = X::pack(f);
-                }
-            }
-            *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;
-        }
+    // NB: macros, not lambdas (with lambdas hipcc keeps the staging registers in scratch); loads are unconditional
+#define WG_ISSUE(TILE)                                                                                            \
+    {                                                                                                             \
+        int tmi_ = (TILE);                                                                                        \
+        const int tile_x_ = tmi_ % p.tiles_x; tmi_ /= p.tiles_x;                                                  \
+        const int tile_y_ = tmi_ % p.tiles_y;                                                                     \
+        const int tile_i_ = tmi_ / p.tiles_y;                                                                     \
+        const int x0_ = tile_x_ << TWL, y0_ = tile_y_ << THL, img0_ = tile_i_ * NI;                               \
+        dy_ok = 0; ah_ok = 0;                                                                                     \
+        _Pragma("unroll") for (int it = 0; it < DY_ITEMS; ++it) {                                                 \
+            const int idx = tid + it * 256;                                                                       \
+            const int m = idx / (CO_S * PPS), pc = idx % (CO_S * PPS);                                            \
+            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);                      \
+            const int gy = y0_ + ty, gx = x0_ + tx, gi = img0_ + img;                                             \
+            const int ch = n0 + pc * EPS;                                                                         \
+            const bool ok = idx < DY_PIECES && gi < p.N && gy < p.H && gx < p.W && ch < p.cout;                   \
+            const long pix = ok ? pix_index(gi, gy, gx, p.H, p.W, p.dy_blk) : 0;                                  \
+            dy_reg[it] = *(const u32x4*)(dyp + pix * p.dy_cs + p.dy_co + (ok ? ch : 0));                          \
+            dy_ok |= (ok ? 1ull : 0ull) << it;                                                                        \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < AH_ITEMS; ++it) {                                                 \
+            const int idx = tid + it * 256;                                                                       \
+            const int pp = idx / (CI_S * PPS), pc = idx % (CI_S * PPS);                                           \
+            const int img = pp / HPI, rem = pp % HPI;                                                             \
+            const int hy = rem / HW2, hx = rem % HW2;                                                             \
+            const int gy = y0_ + hy - 1, gx = x0_ + hx - 1, gi = img0_ + img;                                     \
+            const int ch = k0 + pc * EPS;                                                                         \
+            const bool ok = idx < AH_PIECES && gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ch < p.cin_pad; \
+            const long pix = ok ? pix_index(gi, gy, gx, p.H, p.W, p.in_blk) : 0;                                  \
+            ah_reg[it] = *(const u32x4*)(inp + pix * p.in_cs + p.in_co + (ok ? ch : 0));                          \
+            ah_ok |= (ok ? 1ull : 0ull) << it;                                                                        \
+        }                                                                                                         \
+    }
+#define WG_COMMIT()                                                                                               \
+    {                                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < DY_ITEMS; ++it) {                                                 \
+            const int idx = tid + it * 256;                                                                       \
+            if (idx < DY_PIECES) {                                                                                \
+                const int m = idx / (CO_S * PPS), pc = idx % (CO_S * PPS);                                        \
+                const int sub = pc / PPS, pin = pc % PPS;                                                         \
+                u32x4 v = dy_reg[it];                                                                             \
+                if (!((dy_ok >> it) & 1ull)) v = u32x4{0u, 0u, 0u, 0u};                                             \
+                *(u32x4*)(Dy + sub * 128 * ROWB + m * ROWB + pin * 16) = v;                                       \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < AH_ITEMS; ++it) {                                                 \
+            const int idx = tid + it * 256;                                                                       \
+            if (idx < AH_PIECES) {                                                                                \
+                const int pp = idx / (CI_S * PPS), pc = idx % (CI_S * PPS);                                       \
+                const int sub = pc / PPS, pin = pc % PPS;                                                         \
+                const int ch = k0 + pc * EPS;                                                                     \
+                u32x4 v = ah_reg[it];                                                                             \
+                const bool ok = (ah_ok >> it) & 1ull;                                                               \
+                if (!ok) v = u32x4{0u, 0u, 0u, 0u};                                                               \
+                if (ok && p.prologue == PSSR_PRO_BN_RELU) {                                                       \
+                    float f[EPS];                                                                                 \
+                    X::unpack(v, f);                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
+                        const float4 sc = *(const float4*)(p.pro_scale + ch + e);                                 \
+                        const float4 sh = *(const float4*)(p.pro_shift + ch + e);                                 \
+                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
+                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
+                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
+                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
+                    }                                                                                             \
+                    v = X::pack(f);                                                                               \
+                } else if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                 \
+                    float f[EPS];                                                                                 \
+                    X::unpack(v, f);                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
+                    v = X::pack(f);                                                                               \
+                }                                                                                                 \
+                *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;                                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) WG_ISSUE(tile)
+    for (; tile < p.n_tiles; tile += p.split) {
+        WG_COMMIT()
         __syncthreads();
+        const int nt = tile + p.split;
+        if (PREFETCH && nt < p.n_tiles) WG_ISSUE(nt)
 
         // ---- multiply: 128/KP k-steps x taps
-
         for (int s = 0; s < 128 / KP; ++s) {
             u32x4 af;
             int hb[2];   // halo byte offsets of this lane's reduction rows (tap (0,0))
@@ -188,24 +227,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             }
         }
         __syncthreads();
+        if (!PREFETCH && nt < p.n_tiles) WG_ISSUE(nt)
     }
+#undef WG_ISSUE
+#undef WG_COMMIT
 
-    // ---- combine: dW[n][tap][k] += acc
+    // ---- combine.  parts > 0: this workgroup's partial slab goes to part blockIdx.x with plain stores (every element of
+    // the part is written by exactly one workgroup; pssr_unpack_conv_wgrad_parts sums the parts).  parts == 0: f32
+    // atomics into one caller-zeroed slab.
     const int kcol = k0 + cisub * 32 + (lane & 31);
     if (kcol < p.cin_pad) {
+        float* dst = p.dw + (p.parts > 0 ? (long)blockIdx.x * p.part_stride : 0L);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + cosub * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (n < p.cout) atomicAdd(p.dw + ((long)n * TAPS + t) * p.cin_pad + kcol, acc[t][e]);
+                if (n < p.cout) {
+                    float* q = dst + ((long)n * TAPS + t) * p.cin_pad + kcol;
+                    if (p.parts > 0) *q = acc[t][e];
+                    else atomicAdd(q, acc[t][e]);
+                }
             }
         }
     }
 }
 
 template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
-int launch_t(WgradArgs p, hipStream_t stream) {
+int launch_t(WgradArgs p, hipStream_t stream, int* query) {
     constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
     constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
     constexpr int HP = NI * (TH + 2) * (TW + 2);
@@ -215,14 +264,28 @@ int launch_t(WgradArgs p, hipStream_t stream) {
     p.n_tiles = p.tiles_x * p.tiles_y * p.tiles_i;
     p.co_tiles = cdiv(p.cout, CO_T); p.ci_tiles = cdiv(p.cin_pad, CI_T);
     const int slabs = p.co_tiles * p.ci_tiles;
-    // Every workgroup ends with one f32 atomic add per slab element (147 KB for a 9-tap slab).  At the
-    // chip-wide float-atomic rate (~1.3 TB/s) that traffic hides behind the MFMAs only if a workgroup
-    // reduces over >= 8 pixel tiles first; below 256 workgroups the split is raised to fill the CUs.
-    int split = p.n_tiles / 8;
-    if (split > cdiv(1024, slabs)) split = cdiv(1024, slabs);      // ~1024 workgroups are plenty
-    if (split < 1) split = 1;
-    if (slabs * split < 256) split = cdiv(256, slabs);
-    if (split > p.n_tiles) split = p.n_tiles;
+    int split;
+    if (query != nullptr || p.parts > 0) {
+        // partial-slab mode: ~2 workgroups per CU; every workgroup stores its slab once (plain stores), so the
+        // extra traffic is split * |dW| written + read back by the unpack/reduce pass
+        static int target = 0;
+        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+        split = cdiv(target, slabs);
+        if (split > p.n_tiles) split = p.n_tiles;
+        if (split < 1) split = 1;
+        if (query != nullptr) { *query = split; return PSSR_OK; }
+        PSSR_CHECK(p.parts == split, PSSR_ERR_ARG, "wgrad: dw_parts=%d but this shape needs %d (ask pssr_conv2d_wgrad_parts)", p.parts, split);
+        p.part_stride = (long)p.cout * TAPS * p.cin_pad;
+    } else {
+        // atomic mode: every workgroup ends with one f32 atomic add per slab element; at the chip-wide float-atomic
+        // rate (~1.3 TB/s) that hides behind the MFMAs only if a workgroup reduces over >= 8 pixel tiles first
+        split = p.n_tiles / 8;
+        if (split > cdiv(1024, slabs)) split = cdiv(1024, slabs);
+        if (split < 1) split = 1;
+        if (slabs * split < 256) split = cdiv(256, slabs);
+        if (split > p.n_tiles) split = p.n_tiles;
+        p.part_stride = 0;
+    }
     p.split = split;
     static bool attr_done = false;
     if (!attr_done) {
@@ -235,36 +298,47 @@ int launch_t(WgradArgs p, hipStream_t stream) {
 }
 
 template <typename T, int CO_T, int CI_T, int GEO>
-int launch(const WgradArgs& p, hipStream_t stream) {
-    return p.taps == 9 ? launch_t<T, CO_T, CI_T, GEO, 9>(p, stream) : launch_t<T, CO_T, CI_T, GEO, 1>(p, stream);
+int launch(const WgradArgs& p, hipStream_t stream, int* query) {
+    return p.taps == 9 ? launch_t<T, CO_T, CI_T, GEO, 9>(p, stream, query) : launch_t<T, CO_T, CI_T, GEO, 1>(p, stream, query);
 }
 
 template <typename T, int CO_T, int CI_T>
-int launch_geo(const WgradArgs& a, hipStream_t s) {
+int launch_geo(const WgradArgs& a, hipStream_t s, int* query) {
     const int w = a.W;
-    if (w > 8) return launch<T, CO_T, CI_T, 0>(a, s);
-    if (w > 4) return launch<T, CO_T, CI_T, 1>(a, s);
-    if (w > 2) return launch<T, CO_T, CI_T, 2>(a, s);
+    if (w > 8) return launch<T, CO_T, CI_T, 0>(a, s, query);
+    if (w > 4) return launch<T, CO_T, CI_T, 1>(a, s, query);
+    if (w > 2) return launch<T, CO_T, CI_T, 2>(a, s, query);
     // 2x2 / 1x1 images: the 9x halo blow-up does not fit LDS; training at such sizes is out of scope
     pssr_set_error("wgrad: spatial width %d < 3 is not supported", w);
     return PSSR_ERR_UNSUPPORTED;
 }
 
 template <typename T>
-int launch_shape(const WgradArgs& a, hipStream_t s) {
-    if (a.cout > 64 && a.cin_pad <= 32) return launch_geo<T, 128, 32>(a, s);
-    if (a.cout <= 32) return launch_geo<T, 32, 128>(a, s);
-    return launch_geo<T, 64, 64>(a, s);
+int launch_shape(const WgradArgs& a, hipStream_t s, int* query) {
+    if (a.cout > 64 && a.cin_pad <= 32) return launch_geo<T, 128, 32>(a, s, query);
+    if (a.cout <= 32) return launch_geo<T, 32, 128>(a, s, query);
+    return launch_geo<T, 64, 64>(a, s, query);
 }
 
 }  // namespace
 
-extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream) {
+static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* query);
+
+extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream) { return wgrad_entry(d, stream, nullptr); }
+
+extern "C" int pssr_conv2d_wgrad_parts(const pssr_wgrad_desc* d) {
+    int parts = 0;
+    const int rc = wgrad_entry(d, nullptr, &parts);
+    return rc != PSSR_OK ? rc : parts;
+}
+
+static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* query) {
     PSSR_CHECK(d != nullptr, PSSR_ERR_ARG, "wgrad: null desc");
     PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16, PSSR_ERR_ARG, "wgrad: bad dtype %d", d->dtype);
     const int esz = d->dtype == PSSR_BF16 ? 2 : 4;
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "wgrad: bad shape");
-    PSSR_CHECK(d->dy && d->in && d->dw, PSSR_ERR_ARG, "wgrad: null pointer");
+    PSSR_CHECK(query != nullptr || (d->dy && d->in && d->dw), PSSR_ERR_ARG, "wgrad: null pointer");
+    PSSR_CHECK(d->dw_parts >= 0, PSSR_ERR_ARG, "wgrad: dw_parts=%d", d->dw_parts);
     PSSR_CHECK(d->taps == 9 || d->taps == 1, PSSR_ERR_ARG, "wgrad: taps=%d", d->taps);
     PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % (d->dtype == PSSR_BF16 ? 16 : 8) == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of the K-chunk", d->cin_pad);
     PSSR_CHECK(d->cout > 0 && (d->cout * esz) % 16 == 0, PSSR_ERR_ARG, "wgrad: cout=%d must fill whole 16-byte slots", d->cout);
@@ -278,7 +352,7 @@ extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream)
     a.dy = d->dy; a.dy_cs = d->dy_cstride; a.dy_co = d->dy_coff; a.dy_blk = d->dy_blk; a.cout = d->cout;
     a.in = d->in; a.in_cs = d->in_cstride; a.in_co = d->in_coff; a.in_blk = d->in_blk; a.cin_pad = d->cin_pad;
     a.taps = d->taps; a.prologue = d->prologue; a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
-    a.dw = d->dw;
+    a.dw = d->dw; a.parts = d->dw_parts; a.part_stride = 0;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s) : launch_shape<float>(a, s);
+    return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s, query) : launch_shape<float>(a, s, query);
 }

@@ -58,15 +58,31 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed,
     }
 }
 
-// dW packed layout produced by the wgrad kernel: f32 [n][tap][k_pad]
-__global__ void unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, PackMap m, int k_pad, int accumulate, long total) {
+// dW packed layout produced by the wgrad kernel: f32 [parts][rows][tap][k_pad].  blockIdx.y owns a strided subset of the
+// parts; with one subset (gridDim.y == 1) the sum is stored directly, otherwise the subsets are combined with f32 atomics
+// (the destination is zeroed by `unpack_zero_kernel` first unless the caller accumulates into it).
+__global__ void unpack_kernel(const float* __restrict__ dwp, int parts, long part_stride, float* __restrict__ dw, PackMap m, int k_pad,
+                              int accumulate, long total) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = i % k_pad;
         long t = i / k_pad;
         const int tap = t % m.taps;
         const int n = t / m.taps;
         const long s = m.src_index(k, tap, n);
-        if (s >= 0) dw[s] = accumulate ? dw[s] + dwp[i] : dwp[i];
+        if (s < 0) continue;
+        float v = 0.f;
+        for (int q = blockIdx.y; q < parts; q += gridDim.y) v += dwp[q * part_stride + i];
+        if (gridDim.y > 1) atomicAdd(dw + s, v);
+        else dw[s] = accumulate ? dw[s] + v : v;
+    }
+}
+
+__global__ void unpack_zero_kernel(float* __restrict__ dw, PackMap m, int k_pad, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % k_pad;
+        long t = i / k_pad;
+        const long s = m.src_index(k, (int)(t % m.taps), (int)(t / m.taps));
+        if (s >= 0) dw[s] = 0.f;
     }
 }
 
@@ -101,14 +117,26 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     return PSSR_OK;
 }
 
-extern "C" int pssr_unpack_conv_wgrad(const float* dwp, float* dw, int cout, int cin, int ks, int ci_begin, int ci_count,
-                                      int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
-    PSSR_CHECK(dwp && dw, PSSR_ERR_ARG, "unpack: null pointer");
+extern "C" int pssr_unpack_conv_wgrad_parts(const float* dwp, int parts, int rows, float* dw, int cout, int cin, int ks, int ci_begin,
+                                            int ci_count, int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
+    PSSR_CHECK(dwp && dw && parts > 0 && rows >= cout, PSSR_ERR_ARG, "unpack: bad args");
     PSSR_CHECK(mode == 0 || mode == 2 || mode == 4, PSSR_ERR_ARG, "unpack: mode=%d", mode);
     PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
     const long total = (long)cout * m.taps * k_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwp, dw, m, k_pad, accumulate, total);
+    // enough workgroups to pull the partial slabs at HBM rate: split the parts over blockIdx.y when the slab is small
+    int psplit = 2048 / blocks;
+    if (psplit > parts / 4) psplit = parts / 4;
+    if (psplit < 1) psplit = 1;
+    if (psplit > 1 && !accumulate)
+        hipLaunchKernelGGL(unpack_zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, m, k_pad, total);
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks, psplit), dim3(256), 0, (hipStream_t)stream, dwp, parts, (long)rows * m.taps * k_pad, dw, m,
+                       k_pad, accumulate, total);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
+}
+
+extern "C" int pssr_unpack_conv_wgrad(const float* dwp, float* dw, int cout, int cin, int ks, int ci_begin, int ci_count,
+                                      int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
+    return pssr_unpack_conv_wgrad_parts(dwp, 1, cout, dw, cout, cin, ks, ci_begin, ci_count, mode, n_perm, k_pad, accumulate, stream);
 }

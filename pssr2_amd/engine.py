@@ -356,9 +356,8 @@ class Engine:
         code = p.code
         esz = 2 if code == L.BF16 else 4
         co_eff = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
-        dwp = torch.zeros(co_eff, taps, cin_pad, dtype=torch.float32, device=dy.device)
-        ops.conv2d_wgrad(dy, co_eff, src, cin_pad, taps, dwp, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
-                         pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)
+        dwp = ops.conv2d_wgrad_parts(dy, co_eff, src, cin_pad, taps, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
+                                     pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)
         w = conv_module.weight
         gname = id(w)
         if center:

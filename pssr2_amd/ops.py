@@ -82,9 +82,8 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
     return out
 
 
-def conv2d_wgrad(dy, cout, x, cin_pad, taps, dw, *, n, h, w, dtype, dy_coff=0, in_coff=0, dy_blk=0, in_blk=0,
-                 pro_scale=None, pro_shift=None, gelu_in=False):
-    """dw (f32 [cout, taps, cin_pad], zeroed by the caller) += dy^T (*) prologue(x)."""
+def _wgrad_desc(dy, cout, x, cin_pad, taps, *, n, h, w, dtype, dy_coff=0, in_coff=0, dy_blk=0, in_blk=0, pro_scale=None, pro_shift=None,
+                gelu_in=False):
     d = L.WgradDesc()
     d.dtype, d.n, d.h, d.w = dtype, n, h, w
     d.dy, d.dy_cstride, d.dy_coff, d.dy_blk, d.cout = L.ptr(dy), dy.shape[-1], dy_coff, dy_blk, cout
@@ -92,16 +91,37 @@ def conv2d_wgrad(dy, cout, x, cin_pad, taps, dw, *, n, h, w, dtype, dy_coff=0, i
     d.taps = taps
     d.prologue = L.PRO_GELU if gelu_in else L.PRO_BN_RELU if pro_scale is not None else L.PRO_NONE
     d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
-    d.dw = L.ptr(dw)
+    return d
+
+
+def conv2d_wgrad(dy, cout, x, cin_pad, taps, dw, **kw):
+    """Atomic mode: dw (f32 [cout, taps, cin_pad], zeroed by the caller) += dy^T (*) prologue(x)."""
+    d = _wgrad_desc(dy, cout, x, cin_pad, taps, **kw)
+    d.dw, d.dw_parts = L.ptr(dw), 0
+    L.check(L.lib().pssr_conv2d_wgrad(C.byref(d), L.stream_ptr()), "pssr_conv2d_wgrad")
+    return dw
+
+
+def conv2d_wgrad_parts(dy, cout, x, cin_pad, taps, **kw):
+    """Partial-slab mode: returns dw f32 [parts, cout, taps, cin_pad] (uninitialised workspace filled by the kernel); the
+    parts are summed by ``unpack_conv_wgrad``."""
+    d = _wgrad_desc(dy, cout, x, cin_pad, taps, **kw)
+    parts = L.lib().pssr_conv2d_wgrad_parts(C.byref(d))
+    if parts <= 0:
+        L.check(parts if parts < 0 else -1, "pssr_conv2d_wgrad_parts")
+    dw = torch.empty(parts, cout, taps, cin_pad, dtype=torch.float32, device=dy.device)
+    d.dw, d.dw_parts = L.ptr(dw), parts
     L.check(L.lib().pssr_conv2d_wgrad(C.byref(d), L.stream_ptr()), "pssr_conv2d_wgrad")
     return dw
 
 
 def unpack_conv_wgrad(dw_packed, dw_oihw, *, mode=0, ci_begin=0, ci_count=None, n_perm=None, k_pad, accumulate=False):
+    """dw_packed: f32 [rows, taps, k_pad] or [parts, rows, taps, k_pad] (the parts are summed)."""
     cout, cin, ks, _ = dw_oihw.shape
     ci_count = cin - ci_begin if ci_count is None else ci_count
-    L.check(L.lib().pssr_unpack_conv_wgrad(L.ptr(dw_packed), L.ptr(dw_oihw), cout, cin, ks, ci_begin, ci_count, mode,
-                                           L.ptr(n_perm), k_pad, int(accumulate), L.stream_ptr()), "pssr_unpack_conv_wgrad")
+    parts, rows = (dw_packed.shape[0], dw_packed.shape[1]) if dw_packed.dim() == 4 else (1, dw_packed.shape[0])
+    L.check(L.lib().pssr_unpack_conv_wgrad_parts(L.ptr(dw_packed), parts, rows, L.ptr(dw_oihw), cout, cin, ks, ci_begin, ci_count, mode,
+                                                 L.ptr(n_perm), k_pad, int(accumulate), L.stream_ptr()), "pssr_unpack_conv_wgrad_parts")
     return dw_oihw
 
 

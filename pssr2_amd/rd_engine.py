@@ -260,8 +260,7 @@ class RDEngine(Engine):
         code = p.code
         esz = 2 if code == L.BF16 else 4
         rows = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
-        dwp = torch.zeros(rows, 1, cin_pad, dtype=torch.float32, device=dy.device)
-        ops.conv2d_wgrad(dy, rows, src, cin_pad, 1, dwp, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
+        dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
         w = conv_module.weight
         grads[id(w)] = self._gbuf(w)
         ops.unpack_conv_wgrad(dwp, grads[id(w)], mode=mode, k_pad=cin_pad)

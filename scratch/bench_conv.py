@@ -35,4 +35,8 @@ for name, H, W, ci, co, taps in layers:
         dy = torch.randn(N, H, W, co, device="cuda").to(dt)
         dwp = torch.zeros(co, taps, ci, device="cuda")
         t = timeit(lambda: ops.conv2d_wgrad(dy, co, x, ci, taps, dwp, n=N, h=H, w=W, dtype=code, pro_scale=sc, pro_shift=sh))
-        print(f"{name:20s} wgrad     {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+        t2 = timeit(lambda: ops.conv2d_wgrad_parts(dy, co, x, ci, taps, n=N, h=H, w=W, dtype=code, pro_scale=sc, pro_shift=sh))
+        parts = ops.conv2d_wgrad_parts(dy, co, x, ci, taps, n=N, h=H, w=W, dtype=code, pro_scale=sc, pro_shift=sh)
+        dwo = torch.zeros(co, ci, ks, ks, device="cuda")
+        t3 = timeit(lambda: ops.unpack_conv_wgrad(parts, dwo, k_pad=ci))
+        print(f"{name:20s} wgrad atomic {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s | parts({parts.shape[0]:3d}) {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s | unpack {t3*1e3:6.1f} us")

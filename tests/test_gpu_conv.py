@@ -165,6 +165,7 @@ WG_CASES = [
     (9, 64, 32, 4, 4, 3),
     (2, 64, 256, 16, 16, 1),
     (2, 80, 24, 12, 20, 3),
+    (40, 32, 64, 16, 16, 3),     # many pixel tiles per workgroup: exercises the prefetched tile loop
     (4, 128, 128, 32, 32, 3),
 ]
 
@@ -194,3 +195,10 @@ def test_conv_wgrad(case, dt):
     torch.cuda.synchronize()
     tol = 1e-4 if dt == torch.float32 else 2e-2
     np.testing.assert_allclose(dw.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+    # partial-slab mode (no atomics, no zero-initialised destination): parts summed by the unpack pass
+    parts = ops.conv2d_wgrad_parts(_nhwc(dy, copad, dt), co_eff, _nhwc(yprev, cpad, dt), cpad, ks * ks, n=n, h=h, w=w, dtype=code,
+                                   pro_scale=sc.cuda(), pro_shift=sh.cuda())
+    assert parts.dim() == 4 and parts.shape[1:] == (co_eff, ks * ks, cpad)
+    dw2 = torch.full((cout, cin, ks, ks), 9.0, device="cuda")
+    ops.unpack_conv_wgrad(parts, dw2, k_pad=cpad)
+    np.testing.assert_allclose(dw2.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * ref.abs().max().item())
