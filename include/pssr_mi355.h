@@ -54,6 +54,14 @@ const char* pssr_last_error(void);
 int pssr_pack_conv_weight(const float* w_oihw, void* packed, int cout, int cin, int ks,
                           int ci_begin, int ci_count, int mode, const int32_t* n_perm,
                           int k_pad, int n_pad, int dtype, pssr_stream_t stream);
+/* The same for many weights in one launch (a training step re-packs every conv weight, forward and dgrad form).
+ * `items_dev` is a DEVICE array; fields as the arguments above; `center` != 0 (modes 2/3, ks = 3): `w_oihw` is a 1x1
+ * weight [cout][cin] standing for the centre tap of a 3x3 kernel (ResBlock.respass consumed through the im2col'ed input). */
+typedef struct pssr_pack_item {
+    const float* w; void* packed; const int32_t* n_perm;
+    int32_t cout, cin, ks, ci_begin, ci_count, mode, k_pad, n_pad, dtype, center;
+} pssr_pack_item;
+int pssr_pack_conv_weight_batch(const pssr_pack_item* items_dev, int n_items, pssr_stream_t stream);
 /* bytes needed for a packed weight */
 int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int dtype);
 

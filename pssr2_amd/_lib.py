@@ -52,6 +52,13 @@ class WgradDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    """struct pssr_pack_item (include/pssr_mi355.h)."""
+    _fields_ = [("w", c_void_p), ("packed", c_void_p), ("n_perm", c_void_p),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("ks", C.c_int32), ("ci_begin", C.c_int32), ("ci_count", C.c_int32),
+                ("mode", C.c_int32), ("k_pad", C.c_int32), ("n_pad", C.c_int32), ("dtype", C.c_int32), ("center", C.c_int32)]
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -8,9 +8,16 @@ namespace {
 struct PackMap {
     int cout, cin, ks, ci_begin, ci_count, mode, taps;
     const int32_t* n_perm;
+    int center;   // modes 2/3 only: the tensor is a 1x1 weight seen as the centre tap of a 3x3 kernel (ks must be 3)
     __device__ __forceinline__ long src_index(int k, int tap, int n) const {
         // k: GEMM-K index (un-padded range checked by caller), n: GEMM-N index
         const int kk = ks * ks;
+        if (center) {
+            const int flat = mode == 2 ? k : n, other = mode == 2 ? n : k;
+            if (flat >= ci_count * kk || other >= cout || flat % kk != kk / 2) return -1;
+            const int co = n_perm ? n_perm[other] : other;
+            return (long)co * cin + ci_begin + flat / kk;
+        }
         if (mode == 0) {          // forward: K = ci, N = co
             if (k >= ci_count || n >= cout) return -1;
             const int co = n_perm ? n_perm[n] : n;
@@ -56,6 +63,33 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed,
         const long s = m.src_index(k, tap, n);
         packed[i] = s >= 0 ? (T)w[s] : (T)0.f;
     }
+}
+
+// every weight of a model in ONE launch: blockIdx.y selects the item (a training step re-packs ~100 weights)
+template <typename T>
+__device__ __forceinline__ void pack_item(const pssr_pack_item& it, const PackMap& m) {
+    constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
+    const long total = (long)m.taps * it.k_pad * it.n_pad;
+    T* packed = (T*)it.packed;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = i % EPS;
+        long t = i / EPS;
+        const int slotpos = t % 2; t /= 2;
+        const int n = t % it.n_pad; t /= it.n_pad;
+        const int tap = t % m.taps;
+        const int chunk = t / m.taps;
+        const int slot = slotpos ^ ((n >> 3) & 1);
+        const int k = chunk * KCH + slot * EPS + e;
+        const long s = m.src_index(k, tap, n);
+        packed[i] = s >= 0 ? (T)it.w[s] : (T)0.f;
+    }
+}
+
+__global__ void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
+    const pssr_pack_item it = items[blockIdx.y];
+    const PackMap m{it.cout, it.cin, it.ks, it.ci_begin, it.ci_count, it.mode, it.mode >= 2 ? 1 : it.ks * it.ks, it.n_perm, it.center};
+    if (it.dtype == PSSR_BF16) pack_item<bf16_t>(it, m);
+    else pack_item<float>(it, m);
 }
 
 // dW packed layout produced by the wgrad kernel: f32 [parts][rows][tap][k_pad].  blockIdx.y owns a strided subset of the
@@ -104,7 +138,7 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     const int gk = mode == 0 ? ci_count : (mode == 1 || mode == 3 || mode == 5) ? cout : mode == 4 ? s2dk : ci_count * ks * ks;
     const int gn = mode == 1 ? ci_count : mode == 3 ? ci_count * ks * ks : mode == 5 ? s2dk : cout;
     PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
-    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm, 0};
     const long total = (long)m.taps * k_pad * n_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == PSSR_BF16)
@@ -117,11 +151,18 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     return PSSR_OK;
 }
 
+extern "C" int pssr_pack_conv_weight_batch(const pssr_pack_item* items_dev, int n_items, pssr_stream_t stream) {
+    PSSR_CHECK(items_dev && n_items > 0 && n_items <= 65535, PSSR_ERR_ARG, "pack_batch: bad args");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(96, n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
 extern "C" int pssr_unpack_conv_wgrad_parts(const float* dwp, int parts, int rows, float* dw, int cout, int cin, int ks, int ci_begin,
                                             int ci_count, int mode, const int32_t* n_perm, int k_pad, int accumulate, pssr_stream_t stream) {
     PSSR_CHECK(dwp && dw && parts > 0 && rows >= cout, PSSR_ERR_ARG, "unpack: bad args");
     PSSR_CHECK(mode == 0 || mode == 2 || mode == 4, PSSR_ERR_ARG, "unpack: mode=%d", mode);
-    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm};
+    PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm, 0};
     const long total = (long)cout * m.taps * k_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     // enough workgroups to pull the partial slabs at HBM rate: split the parts over blockIdx.y when the slab is small

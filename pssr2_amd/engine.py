@@ -75,6 +75,20 @@ class _Conv:
             return w3
         return w.detach()
 
+    def item(self, name, dtype):
+        """pssr_pack_item of an already packed (name, dtype) entry, for the batched re-pack."""
+        spec, pw, w = self.specs[name], self.packed[(name, dtype)], self.m.weight
+        center = bool(spec.get("center"))
+        it = L.PackItem()
+        it.w, it.packed = w.data_ptr(), pw.data.data_ptr()
+        perm = spec.get("n_perm")
+        it.n_perm = perm.data_ptr() if perm is not None else None
+        it.cout, it.cin, it.ks = w.shape[0], w.shape[1], 3 if center else w.shape[2]
+        it.ci_begin = spec.get("ci_begin", 0)
+        it.ci_count = spec.get("ci_count") if spec.get("ci_count") is not None else w.shape[1] - it.ci_begin
+        it.mode, it.k_pad, it.n_pad, it.dtype, it.center = spec["mode"], pw.k_pad, pw.n_pad, dtype, int(center)
+        return it
+
     def get(self, name, dtype):
         spec = self.specs[name]
         key = (name, dtype)
@@ -121,6 +135,33 @@ class Engine:
         self.reducer = GradReducer(self._flat_grad, self._goffs, self._gsizes, bucket_bytes, group)
         return self.reducer
 
+    def _begin_backward(self, device):
+        """Zero the flat gradient buffer.  A .grad still aliasing it (no zero_grad since the last backward, or
+        zero_grad(set_to_none=False)) is detached into its own storage first so that accumulation stays correct."""
+        self._grad_layout(device)
+        for prm, view in zip(self.model.parameters(), self._gviews):
+            if prm.grad is not None and prm.grad.data_ptr() == view.data_ptr():
+                prm.grad = prm.grad.clone()
+        self._flat_grad.zero_()
+        if self.reducer is not None:
+            self.reducer.begin()
+
+    def _finish_backward(self, grads):
+        """Publish the gradients.  The engine owns the .grad of its parameters: a parameter without a gradient gets the
+        view of the flat buffer itself (no AccumulateGrad copy, and FusedAdamW / the all-reduce see one flat tensor); an
+        existing gradient is accumulated into, as autograd would."""
+        if self.reducer is not None:
+            self.reducer.finish()
+        with torch.no_grad():
+            for prm, view in zip(self.model.parameters(), self._gviews):
+                if not prm.requires_grad:
+                    continue
+                if prm.grad is None:
+                    prm.grad = view
+                else:
+                    prm.grad.add_(view)
+        return {}
+
     def _gbuf(self, param):
         """Zeroed gradient slot of a parameter (a view of the flat buffer)."""
         return self._gviews[self._gindex[id(param)]]
@@ -157,6 +198,24 @@ class Engine:
         self.pre_perm_long = self.pre_perm.long()
         self._convs = {}
         self._built_for = device
+
+    def _repack_all(self):
+        """Re-pack every cached conv weight whose parameter changed (an optimizer step changes all of them) with ONE
+        launch instead of one per (conv, form).  Entries that were never packed yet stay on the lazy path of _Conv.get."""
+        convs = [c for c in self._convs.values() if c.packed]
+        stale = [(c, key) for c in convs for key in c.packed if c.version.get(key) != c.m.weight._version]
+        if len(stale) < 8:
+            return
+        sig = tuple((id(c), key, c.m.weight.data_ptr(), c.packed[key].data.data_ptr()) for c, key in stale)
+        if getattr(self, "_pack_sig", None) != sig:
+            import ctypes as C
+            arr = (L.PackItem * len(stale))(*[c.item(*key) for c, key in stale])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._pack_table = host.to(stale[0][0].m.weight.device)
+            self._pack_sig = sig
+        L.check(L.lib().pssr_pack_conv_weight_batch(L.ptr(self._pack_table), len(stale), L.stream_ptr()), "pssr_pack_conv_weight_batch")
+        for c, key in stale:
+            c.version[key] = c.m.weight._version
 
     def _conv(self, module, **specs):
         c = self._convs.get(id(module))
@@ -253,12 +312,26 @@ class Engine:
         p.bwd = b
         return b
 
+    def _count_batches(self):
+        """num_batches_tracked += 1 on every BatchNorm2d with ONE kernel: the counters are re-seated as views of one flat
+        int64 tensor (values kept; state_dict / load_state_dict see ordinary buffers)."""
+        bns = [mod for mod in self.model.modules() if isinstance(mod, torch.nn.BatchNorm2d) and mod.num_batches_tracked is not None]
+        if not bns:
+            return
+        key = tuple(b.num_batches_tracked.data_ptr() for b in bns)
+        if getattr(self, "_nbt_key", None) != key:
+            flat = torch.stack([b.num_batches_tracked.detach().reshape(()) for b in bns]).contiguous()
+            for i, b in enumerate(bns):
+                b.num_batches_tracked.data = flat[i]
+            self._nbt_flat = flat
+            self._nbt_key = tuple(b.num_batches_tracked.data_ptr() for b in bns)
+        self._nbt_flat.add_(1)
+
     # ------------------------------------------------------------------ forward
     def _bn_forward(self, p, st, bn_module, count, train):
         if train:
             ops.bn_finalize(st.stats, count, bn_module.weight, bn_module.bias, BN_EPS, BN_MOMENTUM,
                             bn_module.running_mean, bn_module.running_var, st.scale, st.shift, st.mean, st.invstd)
-            bn_module.num_batches_tracked += 1
         else:
             ops.bn_eval_affine(bn_module.weight, bn_module.bias, bn_module.running_mean, bn_module.running_var, BN_EPS,
                                st.scale, st.shift)
@@ -307,9 +380,11 @@ class Engine:
         code = ops.dtype_code(dt)
         self._check_supported(code, h, w, train)
         p = self._plan(n, h, w, dt, x.device)
+        self._repack_all()
         Lv, hid = self.L, self.hidden
         if train:
             p.f64.buf.zero_()
+            self._count_batches()
             ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
         self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
         ops.input_im2col(x, p.xcol, p.bn_in.scale, p.bn_in.shift, code)
@@ -367,7 +442,8 @@ class Engine:
             return
         if gname not in grads:
             grads[gname] = self._gbuf(w)          # zeroed at the start of backward
-        ops.unpack_conv_wgrad(dwp, grads[gname], mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
+        # the slot was zeroed with the whole flat buffer at the start of backward: accumulate (no separate zero pass)
+        ops.unpack_conv_wgrad(dwp, grads[gname], mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad, accumulate=True)
 
     def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
         """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc."""
@@ -381,11 +457,10 @@ class Engine:
         last = blk.bn[-1]
         bn_last = module.conv[3 * (nl - 1) + 1]
         ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
-        dgam = torch.empty_like(bn_last.weight)
-        dbet = torch.empty_like(bn_last.bias)
+        dgam, dbet = self._gbuf(bn_last.weight), self._gbuf(bn_last.bias)
         ops.bn_bwd_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
         grads[id(bn_last.weight)], grads[id(bn_last.bias)] = dgam, dbet
-        grads[id(module.respass.bias)] = dbet.clone()       # d(respass bias) = sum dz = dbeta of the last BN
+        grads[id(module.respass.bias)] = dbet               # d(respass bias) = sum dz = dbeta of the last BN (copied by _ready)
         ops.bn_bwd_apply(dz, blk.y[-1], last.ca, last.cb, last.cc, dy, npix, blk.c, code)
         for k in range(nl - 1, 0, -1):
             conv = module.conv[3 * k]
@@ -396,7 +471,7 @@ class Engine:
             ops.conv2d(dy, blk.c, pwd, g, blk.c, n=n, h=hh, w=ww, epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS,
                        aux=blk.y[k - 1], aux_scale=prev.scale, aux_shift=prev.shift, aux_mean=prev.mean, aux_invstd=prev.invstd,
                        stats=prev.bstats)
-            dgam, dbet = torch.empty_like(bn_prev.weight), torch.empty_like(bn_prev.bias)
+            dgam, dbet = self._gbuf(bn_prev.weight), self._gbuf(bn_prev.bias)
             ops.bn_bwd_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
             grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
             ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy, npix, blk.c, code)
@@ -426,15 +501,7 @@ class Engine:
         Lv, hid, r = self.L, self.hidden, self.r
         h0 = hid[0]
         grads = {}
-        self._grad_layout(dev)
-        for prm, view in zip(m.parameters(), self._gviews):
-            # a .grad still aliasing our buffer (zero_grad(set_to_none=False) or deliberate accumulation):
-            # detach it first so that autograd's accumulation stays correct
-            if prm.grad is not None and prm.grad.data_ptr() == view.data_ptr():
-                prm.grad = prm.grad.clone()
-        self._flat_grad.zero_()
-        if self.reducer is not None:
-            self.reducer.begin()
+        self._begin_backward(dev)
         rec = m.reconstruction
         H, W = h * r, w * r
         dout = dout.contiguous().float()
@@ -496,10 +563,8 @@ class Engine:
         st = p.bn_in
         st.bstats.zero_()
         ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
-        dgam, dbet = torch.empty_like(m.norm.weight), torch.empty_like(m.norm.bias)
+        dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         ops.bn_bwd_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
         self._ready(grads, list(m.norm.parameters()))
-        if self.reducer is not None:
-            self.reducer.finish()
-        return grads
+        return self._finish_backward(grads)

@@ -62,6 +62,8 @@ class _EngineFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        # the engine writes every parameter gradient into one flat buffer and publishes the views as .grad itself
+        # (Engine._finish_backward): autograd receives no per-parameter gradients, so nothing is cloned or re-accumulated
         grads = ctx.engine.backward(dout)
         out = []
         for pid, shp in zip(ctx.param_ids, ctx.shapes):

@@ -263,7 +263,7 @@ class RDEngine(Engine):
         dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
         w = conv_module.weight
         grads[id(w)] = self._gbuf(w)
-        ops.unpack_conv_wgrad(dwp, grads[id(w)], mode=mode, k_pad=cin_pad)
+        ops.unpack_conv_wgrad(dwp, grads[id(w)], mode=mode, k_pad=cin_pad, accumulate=True)     # slot zeroed at the start of backward
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train):
@@ -279,9 +279,11 @@ class RDEngine(Engine):
         code = ops.dtype_code(dt)
         self._check_supported_rd(code, h, w, train)
         p = self._plan(n, h, w, dt, x.device)
+        self._repack_all()
         hid, nd = self.hidden, len(self.hidden)
         if train:
             p.f64.buf.zero_()
+            self._count_batches()
             ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
         self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
         ops.input_im2col(x, p.xcol, p.bn_in.scale, p.bn_in.shift, code)
@@ -409,13 +411,7 @@ class RDEngine(Engine):
         n, h, w, code = p.n, p.h, p.w, p.code
         hid, nd, r, h0 = self.hidden, len(self.hidden), self.r, self.h0
         grads = {}
-        self._grad_layout(dev)
-        for prm, view in zip(m.parameters(), self._gviews):
-            if prm.grad is not None and prm.grad.data_ptr() == view.data_ptr():
-                prm.grad = prm.grad.clone()
-        self._flat_grad.zero_()
-        if self.reducer is not None:
-            self.reducer.begin()
+        self._begin_backward(dev)
         rec = m.reconstruction
         H, W = h * r, w * r
         dout = dout.contiguous().float()
@@ -500,10 +496,8 @@ class RDEngine(Engine):
         stn = p.bn_in
         stn.bstats.zero_()
         ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
-        dgam, dbet = torch.empty_like(m.norm.weight), torch.empty_like(m.norm.bias)
+        dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         ops.bn_bwd_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
         self._ready(grads, list(m.norm.parameters()))
-        if self.reducer is not None:
-            self.reducer.finish()
-        return grads
+        return self._finish_backward(grads)
