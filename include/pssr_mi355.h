@@ -346,6 +346,24 @@ int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float*
                  const float* w_fc, int n, int c, int hw, float* du, float* dgamma, float* db_fc, float* dw_fc, float* add,
                  pssr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Reconstruction.conv (pssr/models/_blocks.py:11,17 + "x*128+128", pssr/models/resunet.py:95) for C_out = 1..3: dedicated
+ * streaming kernels (csrc/head_conv.hip) for the conv that reads the largest tensor of the network; bf16 storage only.
+ * `act` is the NHWC activation in blocked pixel order (log2 r = blk, see pssr_conv_desc), `g` the incoming f32 NCHW
+ * gradient of the network output (scaled by g_scale = the output scale, 128).
+ *   fwd:   out_nchw = (conv3x3(act, w) + bias) * out_scale + out_shift
+ *   dgrad: dact = (act > 0) * conv3x3_transposed(g * g_scale, w)        (ReLU of Reconstruction.pre fused)
+ *   wgrad: dw_oihw += sum_pixels (g * g_scale) (x) shifted act            (f32 atomics into the caller-zeroed gradient)
+ */
+int pssr_head_conv_fwd(const void* act, int act_cs, int act_co, int blk, const float* w_oihw, const float* bias,
+                       float* out_nchw, int n, int h, int w, int cin, int cout, float out_scale, float out_shift,
+                       int dtype, pssr_stream_t stream);
+int pssr_head_conv_dgrad(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co,
+                         void* dact, int d_cs, int d_co, int blk, int n, int h, int w, int cin, int cout, int dtype,
+                         pssr_stream_t stream);
+int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, int act_cs, int act_co, int blk,
+                         float* dw_oihw, int n, int h, int w, int cin, int cout, int dtype, pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

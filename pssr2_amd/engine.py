@@ -190,7 +190,7 @@ class Engine:
         self.r = m.reconstruction.scale
         self.blk = _log2(self.r)
         self.xc = ops.pad_to(9 * self.cin, 16)
-        h0 = self.hidden[0]
+        h0 = self.h0 = self.hidden[0]
         r2 = self.r * self.r
         # sub-pixel-major channel order of Reconstruction.pre: n' = sub*h0 + c  <-  n = c*r2 + sub
         idx = torch.arange(r2 * h0)
@@ -405,25 +405,81 @@ class Engine:
             ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
             blk = p.dec[l]
             self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train)
-        # head: relu(conv3x3([dec0 | x0])) in sub-pixel-major channel order == pixel-shuffled, blocked layout
-        rec = m.reconstruction
-        h0 = hid[0]
         feat = p.dec[0].out if Lv > 1 else p.enc[0].out
+        out = self._head_forward(p, feat, x)
+        self.saved = (p, x) if train else None
+        return out
+
+    # ------------------------------------------------------------------ reconstruction head (shared with RDEngine)
+    def _head_forward(self, p, feat, x):
+        """relu(conv3x3([feat | x0])) in sub-pixel-major channel order (== pixel-shuffled, blocked layout) -> conv3x3 ->
+        x*128+128 (pssr/models/_blocks.py:15-18, pssr/models/resunet.py:90-95)."""
+        rec = self.model.reconstruction
+        n, h, w, code, h0, r = p.n, p.h, p.w, p.code, self.h0, self.r
         cpre = self._conv(rec.pre,
                           fwd0=dict(mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
                           fwd1=dict(mode=2, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm),
                           dgrad0=dict(mode=1, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
                           dgrad1=dict(mode=3, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm))
         p.pre_bias = rec.pre.bias.detach()[self.pre_perm_long].contiguous()
-        ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, self.r * self.r * h0, n=n, h=h, w=w, bias=p.pre_bias,
+        ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias,
                    x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)
-        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
-        out = torch.empty(n, self.cout, h * self.r, w * self.r, dtype=torch.float32, device=x.device)
-        pre_hr = p.pre.view(n, h * self.r, w * self.r, h0)
-        ops.conv2d(pre_hr, h0, cfin.get("fwd", code), out, self.cout, n=n, h=h * self.r, w=w * self.r, bias=rec.conv.bias,
-                   epilogue=L.EPI_FINAL, in0_blk=self.blk, out_scale=128.0, out_shift=128.0)
-        self.saved = (p, x) if train else None
+        out = torch.empty(n, self.cout, h * r, w * r, dtype=torch.float32, device=x.device)
+        pre_hr = p.pre.view(n, h * r, w * r, h0)
+        if ops.head_conv_supported(code, h0, self.cout):
+            ops.head_conv_fwd(pre_hr, self.blk, rec.conv.weight, rec.conv.bias, out, n, h * r, w * r, h0, self.cout, 128.0, 128.0, code)
+        else:
+            cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
+            ops.conv2d(pre_hr, h0, cfin.get("fwd", code), out, self.cout, n=n, h=h * r, w=w * r, bias=rec.conv.bias,
+                       epilogue=L.EPI_FINAL, in0_blk=self.blk, out_scale=128.0, out_shift=128.0)
         return out
+
+    def _head_backward(self, p, bw, grads, dout, feat, dfeat):
+        """Backward of the head: parameter gradients of Reconstruction, d(feat) into `dfeat`, d(xcol) into bw.dxcol_b."""
+        rec = self.model.reconstruction
+        n, h, w, code, h0, r = p.n, p.h, p.w, p.code, self.h0, self.r
+        dev = dout.device
+        H, W = h * r, w * r
+        dout = dout.contiguous().float()
+        pre_hr = p.pre.view(n, H, W, h0)
+        dpre_hr = bw.dpre.view(n, H, W, h0)
+        if ops.head_conv_supported(code, h0, self.cout):
+            # final conv straight from the f32 NCHW gradient ("x*128+128" folded into g_scale)
+            bw.sum64.zero_()
+            ops.channel_stats_nchw(dout, bw.sum64, 128.0, 0.0)
+            gb = torch.empty(2 * self.cout, dtype=torch.float32, device=dev)
+            ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * 2 * self.cout], gb)
+            grads[id(rec.conv.bias)] = gb[:self.cout]
+            gw = grads[id(rec.conv.weight)] = self._gbuf(rec.conv.weight)
+            ops.head_conv_wgrad(dout, 128.0, pre_hr, self.blk, gw, n, H, W, h0, self.cout, code)
+            ops.head_conv_dgrad(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, n, H, W, h0, self.cout, code)
+        else:
+            ops.nchw_to_nhwc(dout, bw.g_hr, 128.0, code)
+            bw.sum64.zero_()
+            ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
+            gb = torch.empty(16, dtype=torch.float32, device=dev)
+            ops.f64_to_f32(bw.sum64, gb)
+            grads[id(rec.conv.bias)] = gb[:self.cout]
+            self._wgrad(p, grads, rec.conv, bw.g_hr, 16, pre_hr, h0, 9, in_blk=self.blk, hh=H, ww=W)
+            cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
+            ops.conv2d(bw.g_hr, 16, cfin.get("dgrad", code), dpre_hr, h0, n=n, h=H, w=W, epilogue=L.EPI_DGRAD_MASK,
+                       aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
+        # ---- Reconstruction.pre (two sources)
+        cpre_n = r * r * h0
+        bw.sum64.zero_()
+        ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
+        gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
+        ops.f64_to_f32(bw.sum64, gpb)
+        gb_pre = torch.empty_like(gpb)
+        gb_pre[self.pre_perm_long] = gpb
+        grads[id(rec.pre.bias)] = gb_pre
+        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
+        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
+                    n_perm=self.pre_perm, hh=h, ww=w)
+        self._ready(grads, list(rec.parameters()))
+        cpre = self._convs[id(rec.pre)]
+        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
+        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,
@@ -502,40 +558,8 @@ class Engine:
         h0 = hid[0]
         grads = {}
         self._begin_backward(dev)
-        rec = m.reconstruction
-        H, W = h * r, w * r
-        dout = dout.contiguous().float()
-        # ---- final conv (x*128+128 folded into the incoming gradient)
-        ops.nchw_to_nhwc(dout, bw.g_hr, 128.0, code)
-        bw.sum64.zero_()
-        ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
-        gb = torch.empty(16, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64, gb)
-        grads[id(rec.conv.bias)] = gb[:self.cout].clone()
-        pre_hr = p.pre.view(n, H, W, h0)
-        self._wgrad(p, grads, rec.conv, bw.g_hr, 16, pre_hr, h0, 9, in_blk=self.blk, hh=H, ww=W)
-        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
-        dpre_hr = bw.dpre.view(n, H, W, h0)
-        ops.conv2d(bw.g_hr, 16, cfin.get("dgrad", code), dpre_hr, h0, n=n, h=H, w=W, epilogue=L.EPI_DGRAD_MASK,
-                   aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
-        # ---- Reconstruction.pre (two sources)
-        cpre_n = r * r * h0
-        bw.sum64.zero_()
-        ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
-        gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64, gpb)
-        gb_pre = torch.empty_like(gpb)
-        gb_pre[self.pre_perm_long] = gpb
-        grads[id(rec.pre.bias)] = gb_pre
         feat = p.dec[0].out if Lv > 1 else p.enc[0].out
-        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
-        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
-                    n_perm=self.pre_perm, hh=h, ww=w)
-        self._ready(grads, list(rec.parameters()))
-        cpre = self._convs[id(rec.pre)]
-        dfeat = bw.dout[0]
-        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
-        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
+        self._head_backward(p, bw, grads, dout, feat, bw.dout[0])
         # ---- decoder, bottom-up in the data-flow sense (level 0 first)
         for l in range(0, Lv - 1):
             blk = p.dec[l]

@@ -378,3 +378,24 @@ def ese_bwd(A, gate, u, gamma, s_mean, w_fc, hw, du, dgamma, db_fc, dw_fc, add):
     n, c = A.shape
     L.check(L.lib().pssr_ese_bwd(L.ptr(A), L.ptr(gate), L.ptr(u), L.ptr(gamma), L.ptr(s_mean), L.ptr(w_fc), n, c, hw, L.ptr(du),
                                  L.ptr(dgamma), L.ptr(db_fc), L.ptr(dw_fc), L.ptr(add), L.stream_ptr()), "pssr_ese_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# Reconstruction.conv for C_out <= 3 (csrc/head_conv.hip), bf16 storage
+def head_conv_supported(dtype, cin, cout):
+    return dtype == L.BF16 and 1 <= cout <= 3 and cin % 32 == 0 and 32 <= cin <= 128
+
+
+def head_conv_fwd(act, blk, weight, bias, out, n, h, w, cin, cout, out_scale, out_shift, dtype, act_coff=0):
+    L.check(L.lib().pssr_head_conv_fwd(L.ptr(act), act.shape[-1], act_coff, blk, L.ptr(weight), L.ptr(bias), L.ptr(out), n, h, w, cin, cout,
+                                       C.c_float(out_scale), C.c_float(out_shift), dtype, L.stream_ptr()), "pssr_head_conv_fwd")
+
+
+def head_conv_dgrad(g, g_scale, weight, act, dact, blk, n, h, w, cin, cout, dtype):
+    L.check(L.lib().pssr_head_conv_dgrad(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
+                                         blk, n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_dgrad")
+
+
+def head_conv_wgrad(g, g_scale, act, blk, dw, n, h, w, cin, cout, dtype):
+    L.check(L.lib().pssr_head_conv_wgrad(L.ptr(g), C.c_float(g_scale), L.ptr(act), act.shape[-1], 0, blk, L.ptr(dw), n, h, w, cin, cout, dtype,
+                                         L.stream_ptr()), "pssr_head_conv_wgrad")

@@ -331,22 +331,7 @@ class RDEngine(Engine):
                 ops.pixel_shuffle(blk.out, p.cat[k + 1], n, *p.dims[k], hid[k] // (r * r), r, code)
             else:
                 ops.pixel_shuffle(blk.out, p.feat, n, *p.dims[k], self.h0, r, code)
-        # ---- head (as Engine.forward)
-        rec = m.reconstruction
-        h0 = self.h0
-        cpre = self._conv(rec.pre,
-                          fwd0=dict(mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
-                          fwd1=dict(mode=2, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm),
-                          dgrad0=dict(mode=1, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
-                          dgrad1=dict(mode=3, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm))
-        p.pre_bias = rec.pre.bias.detach()[self.pre_perm_long].contiguous()
-        ops.conv2d(p.feat, h0, cpre.get("fwd0", code), p.pre, self.r * self.r * h0, n=n, h=h, w=w, bias=p.pre_bias,
-                   x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)
-        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
-        out = torch.empty(n, self.cout, h * self.r, w * self.r, dtype=torch.float32, device=x.device)
-        pre_hr = p.pre.view(n, h * self.r, w * self.r, h0)
-        ops.conv2d(pre_hr, h0, cfin.get("fwd", code), out, self.cout, n=n, h=h * self.r, w=w * self.r, bias=rec.conv.bias,
-                   epilogue=L.EPI_FINAL, in0_blk=self.blk, out_scale=128.0, out_shift=128.0)
+        out = self._head_forward(p, p.feat, x)
         self.saved = (p, x) if train else None
         return out
 
@@ -412,37 +397,7 @@ class RDEngine(Engine):
         hid, nd, r, h0 = self.hidden, len(self.hidden), self.r, self.h0
         grads = {}
         self._begin_backward(dev)
-        rec = m.reconstruction
-        H, W = h * r, w * r
-        dout = dout.contiguous().float()
-        # ---- head (as Engine.backward)
-        ops.nchw_to_nhwc(dout, bw.g_hr, 128.0, code)
-        bw.sum64.zero_()
-        ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
-        gb = torch.empty(16, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64, gb)
-        grads[id(rec.conv.bias)] = gb[:self.cout].clone()
-        pre_hr = p.pre.view(n, H, W, h0)
-        self._wgrad(p, grads, rec.conv, bw.g_hr, 16, pre_hr, h0, 9, in_blk=self.blk, hh=H, ww=W)
-        cfin = self._conv(rec.conv, fwd=dict(mode=0), dgrad=dict(mode=1))
-        dpre_hr = bw.dpre.view(n, H, W, h0)
-        ops.conv2d(bw.g_hr, 16, cfin.get("dgrad", code), dpre_hr, h0, n=n, h=H, w=W, epilogue=L.EPI_DGRAD_MASK,
-                   aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
-        cpre_n = r * r * h0
-        bw.sum64.zero_()
-        ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
-        gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64, gpb)
-        gb_pre = torch.empty_like(gpb)
-        gb_pre[self.pre_perm_long] = gpb
-        grads[id(rec.pre.bias)] = gb_pre
-        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
-        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
-                    n_perm=self.pre_perm, hh=h, ww=w)
-        self._ready(grads, list(rec.parameters()))
-        cpre = self._convs[id(rec.pre)]
-        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), bw.dfeat, h0, n=n, h=h, w=w)
-        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
+        self._head_backward(p, bw, grads, dout, p.feat, bw.dfeat)
         # ---- decoder, last block first
         for k in range(nd - 1, -1, -1):
             blk = p.dec[k]
