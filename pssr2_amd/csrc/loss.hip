@@ -274,6 +274,270 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-blocked variants for a compile-time window K: a thread produces SEG consecutive outputs of a 1-D filter pass
+// from a sliding window of SEG+K-1 inputs held in registers (6x fewer LDS reads than one output per thread), all tap
+// loops unrolled (window weights come from scalar registers).  Same LDS images and arithmetic order per output as above.
+template <int K, int SEG, int NQ>
+__device__ __forceinline__ void fir_seg(const float (*v)[SEG + K - 1], const Win& win, float (*out)[SEG]) {
+#pragma unroll
+    for (int o = 0; o < SEG; ++o)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < K; ++t) s = fmaf(win.g[t], v[q][o + t], s);
+            out[q][o] = s;
+        }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                  Win win, float C1, float C2, double* sums, double* l1_sum) {
+    constexpr int halo = K - 1, IN = TS + halo, SEG = 8, NS = TS / SEG;
+    extern __shared__ float lds[];
+    float* xs = lds;
+    float* ys = xs + IN * IN;
+    float* hp = ys + IN * IN;                  // [5][IN][TS]
+    const int plane = blockIdx.z;
+    const int oy0 = blockIdx.y * TS, ox0 = blockIdx.x * TS;
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const int tid = threadIdx.x;
+    float l1 = 0.f;
+    for (int i = tid; i < IN * IN; i += 256) {
+        const int r = i / IN, c = i % IN;
+        const int gy = oy0 + r, gx = ox0 + c;
+        float xv = 0.f, yv = 0.f;
+        if (gy < H && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        xs[i] = xv; ys[i] = yv;
+    }
+    if (l1_sum) {
+        constexpr int r5 = K / 2;
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int gy = oy0 + i / TS, gx = ox0 + i % TS;
+            if (gy < H && gx < W) {
+                float sy = 0.f, sx = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int yy = gy + t - r5, xx = gx + t - r5;
+                    if (yy >= 0 && yy < H) sy += win.g[t];
+                    if (xx >= 0 && xx < W) sx += win.g[t];
+                }
+                l1 += fabsf(xp[(long)gy * W + gx] - yp[(long)gy * W + gx]) * sy * sx;
+            }
+        }
+    }
+    __syncthreads();
+    // horizontal pass: item = (row, segment of SEG output columns)
+    for (int it = tid; it < IN * NS; it += 256) {
+        const int r = it / NS, c0 = (it % NS) * SEG;
+        float v[5][SEG + K - 1];
+#pragma unroll
+        for (int j = 0; j < SEG + K - 1; ++j) {
+            const float a = xs[r * IN + c0 + j], b = ys[r * IN + c0 + j];
+            v[0][j] = a; v[1][j] = b; v[2][j] = a * a; v[3][j] = b * b; v[4][j] = a * b;
+        }
+        float o[5][SEG];
+        fir_seg<K, SEG, 5>(v, win, o);
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) hp[q * IN * TS + r * TS + c0 + j] = o[q][j];
+    }
+    __syncthreads();
+    float cs_acc = 0.f, ss_acc = 0.f;
+    // vertical pass: item = (column, segment of SEG output rows)
+    for (int it = tid; it < TS * NS; it += 256) {
+        const int c = it % TS, r0 = (it / TS) * SEG;
+        float v[5][SEG + K - 1];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[q][j] = hp[q * IN * TS + (r0 + j) * TS + c];
+        float m[5][SEG];
+        fir_seg<K, SEG, 5>(v, win, m);
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            if (oy0 + r0 + j >= VH || ox0 + c >= VW) continue;
+            const float mx = m[0][j], my = m[1][j];
+            const float sxx = m[2][j] - mx * mx, syy = m[3][j] - my * my, sxy = m[4][j] - mx * my;
+            const float cs = (2.f * sxy + C2) / (sxx + syy + C2);
+            const float lum = (2.f * mx * my + C1) / (mx * mx + my * my + C1);
+            cs_acc += cs; ss_acc += lum * cs;
+        }
+    }
+    __shared__ float red[3][256];
+    red[0][tid] = cs_acc; red[1][tid] = ss_acc; red[2][tid] = l1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(sums + plane * 2, (double)red[0][0]);
+        atomicAdd(sums + plane * 2 + 1, (double)red[1][0]);
+        if (l1_sum) atomicAdd(l1_sum, (double)red[2][0]);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void ssim_bwd_k(const float* __restrict__ X, const float* __restrict__ Y, int H, int W, Win win,
+                                                  float C1, float C2, const float* __restrict__ wts, int use_ssim,
+                                                  const float* __restrict__ dcoarse, int HC, int WC, const float* l1_coef_p,
+                                                  float* __restrict__ dX) {
+    constexpr int halo = K - 1, AD = TS + halo, IN = TS + 2 * halo;
+    constexpr int SA = 7, NSA = (AD + SA - 1) / SA;       // segments over the AD-wide adjoint region (42 = 6 x 7 for K = 11)
+    constexpr int SEG = 8, NS = TS / SEG;                 // segments over the TS-wide output region
+    constexpr int ADP = NSA * SA;                         // padded row length of the h-pass image
+    extern __shared__ float lds[];
+    float* xs = lds;                       // [IN][IN + pad]
+    constexpr int INP = IN + SA;           // row pitch with room for the last (partial) segment's window
+    float* ys = xs + IN * INP;
+    float* hp = ys + IN * INP;             // [5][IN][ADP]  -> later th [3][AD][TS]
+    float* ad = lds;                       // [3][AD][AD] adjoint maps: alias xs / ys, which are dead after the horizontal pass
+    constexpr int ADR = AD, ADC = AD;
+    static_assert(3 * AD * AD <= 2 * IN * INP, "adjoint maps must fit into the input images");
+    const int plane = blockIdx.z;
+    const int qy0 = blockIdx.y * TS, qx0 = blockIdx.x * TS;
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const int tid = threadIdx.x;
+    const float wt = wts[plane];
+    for (int i = tid; i < IN * INP; i += 256) {
+        const int r = i / INP, c = i % INP;
+        const int gy = qy0 - halo + r, gx = qx0 - halo + c;
+        float xv = 0.f, yv = 0.f;
+        if (c < IN && gy >= 0 && gy < H && gx >= 0 && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        xs[i] = xv; ys[i] = yv;
+    }
+    __syncthreads();
+    // horizontal pass over [IN rows][AD cols]
+    for (int it = tid; it < IN * NSA; it += 256) {
+        const int r = it / NSA, c0 = (it % NSA) * SA;
+        float v[5][SA + K - 1];
+#pragma unroll
+        for (int j = 0; j < SA + K - 1; ++j) {
+            const float a = xs[r * INP + c0 + j], b = ys[r * INP + c0 + j];
+            v[0][j] = a; v[1][j] = b; v[2][j] = a * a; v[3][j] = b * b; v[4][j] = a * b;
+        }
+        float o[5][SA];
+        fir_seg<K, SA, 5>(v, win, o);
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < SA; ++j) hp[q * IN * ADP + r * ADP + c0 + j] = o[q][j];
+    }
+    __syncthreads();
+    // vertical pass + adjoint maps at [AD rows][AD cols]; stored at column offset 0, rows 0..AD-1 of the padded image
+    for (int it = tid; it < AD * NSA; it += 256) {
+        const int c = it % AD, r0 = (it / AD) * SA;
+        float v[5][SA + K - 1];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < SA + K - 1; ++j) {
+                const int rr = r0 + j;
+                v[q][j] = rr < IN ? hp[q * IN * ADP + rr * ADP + c] : 0.f;
+            }
+        float m[5][SA];
+        fir_seg<K, SA, 5>(v, win, m);
+#pragma unroll
+        for (int j = 0; j < SA; ++j) {
+            const int r = r0 + j;
+            if (r >= AD) continue;
+            const int py = qy0 - halo + r, px = qx0 - halo + c;
+            float a = 0.f, b = 0.f, cc = 0.f;
+            if (py >= 0 && py < VH && px >= 0 && px < VW) {
+                const float mx = m[0][j], my = m[1][j];
+                const float sxx = m[2][j] - mx * mx, syy = m[3][j] - my * my, sxy = m[4][j] - mx * my;
+                const float Dcs = sxx + syy + C2, cs = (2.f * sxy + C2) / Dcs;
+                const float dcs_dmx = 2.f * (cs * mx - my) / Dcs, dcs_dexx = -cs / Dcs, dcs_dexy = 2.f / Dcs;
+                if (use_ssim) {
+                    const float Dl = mx * mx + my * my + C1, lum = (2.f * mx * my + C1) / Dl;
+                    const float dl_dmx = 2.f * (my - lum * mx) / Dl;
+                    a = wt * (lum * dcs_dmx + cs * dl_dmx); b = wt * lum * dcs_dexx; cc = wt * lum * dcs_dexy;
+                } else {
+                    a = wt * dcs_dmx; b = wt * dcs_dexx; cc = wt * dcs_dexy;
+                }
+            }
+            ad[0 * ADR * ADC + r * ADC + c] = a; ad[1 * ADR * ADC + r * ADC + c] = b; ad[2 * ADR * ADC + r * ADC + c] = cc;
+        }
+    }
+    __syncthreads();
+    // transposed filter, horizontal: th[r][q] = sum_t g[t] * ad[r][q + halo - t] = sum_u g[K-1-u] * ad[r][q + u]
+    float* th = hp;                        // [3][AD + SEG][TS]
+    constexpr int THR = AD + SEG;
+    for (int it = tid; it < AD * NS; it += 256) {
+        const int r = it / NS, c0 = (it % NS) * SEG;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float v[SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[j] = ad[q * ADR * ADC + r * ADC + c0 + j];
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) s = fmaf(win.g[t], v[o + halo - t], s);
+                th[q * THR * TS + r * TS + c0 + o] = s;
+            }
+        }
+    }
+    __syncthreads();
+    const float l1c = l1_coef_p ? l1_coef_p[0] : 0.f;
+    constexpr int r5 = K / 2;
+    float* dxp = dX + (long)plane * H * W;
+    for (int it = tid; it < TS * NS; it += 256) {
+        const int c = it % TS, r0 = (it / TS) * SEG;
+        float s[3][SEG];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float v[SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[j] = th[q * THR * TS + (r0 + j) * TS + c];
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) a = fmaf(win.g[t], v[o + halo - t], a);
+                s[q][o] = a;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+            const int r = r0 + o;
+            const int gy = qy0 + r, gx = qx0 + c;
+            if (gy >= H || gx >= W) continue;
+            const float xv = xp[(long)gy * W + gx], yv = yp[(long)gy * W + gx];      // (the LDS copies were overwritten by `ad`)
+            float g = s[0][o] + 2.f * xv * s[1][o] + yv * s[2][o];
+            if (dcoarse) {
+                const int cy = (gy + (H & 1)) >> 1, cx = (gx + (W & 1)) >> 1;
+                g += 0.25f * dcoarse[((long)plane * HC + cy) * WC + cx];
+            }
+            if (l1c != 0.f) {
+                float sy = 0.f, sx = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int yy = gy + t - r5, xx = gx + t - r5;
+                    if (yy >= 0 && yy < H) sy += win.g[t];
+                    if (xx >= 0 && xx < W) sx += win.g[t];
+                }
+                const float d = xv - yv;
+                g += l1c * sy * sx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            }
+            dxp[(long)gy * W + gx] = g;
+        }
+    }
+}
+
+template <int K> constexpr size_t bwd_lds_k() {
+    constexpr int halo = K - 1, AD = TS + halo, IN = TS + 2 * halo, SA = 7, NSA = (AD + SA - 1) / SA, ADP = NSA * SA, INP = IN + SA;
+    return (size_t)(2 * IN * INP + 5 * IN * ADP) * sizeof(float);
+}
+
 Win make_win(const float* g, int k) {
     Win w; w.k = k;
     for (int i = 0; i < MAXW; ++i) w.g[i] = i < k ? g[i] : 0.f;
@@ -293,9 +557,17 @@ int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w
     // when the L1 term is requested the tiles must cover the whole image, not only the valid region
     const int eh = l1_sum ? h : h - k + 1, ew = l1_sum ? w : w - k + 1;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ssim_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; }
-    hipLaunchKernelGGL(ssim_fwd_kernel<0>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
-                       make_win(win_host, k), c1, c2, sums, l1_sum);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)ssim_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute((const void*)ssim_fwd_k<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr = true;
+    }
+    if (k == 11)
+        hipLaunchKernelGGL(ssim_fwd_k<11>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                           make_win(win_host, k), c1, c2, sums, l1_sum);
+    else
+        hipLaunchKernelGGL(ssim_fwd_kernel<0>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                           make_win(win_host, k), c1, c2, sums, l1_sum);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -328,9 +600,17 @@ int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w
     const size_t lds = (size_t)(2 * IN * IN + 5 * IN * AD + 3 * AD * AD) * sizeof(float);
     PSSR_CHECK(lds <= 156 * 1024, PSSR_ERR_UNSUPPORTED, "ssim_level_bwd: window %d needs %zu bytes of LDS", k, lds);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ssim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; }
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
-                       make_win(win_host, k), c1, c2, wts, use_ssim, dcoarse, hc, wc, l1_coef, dx);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)ssim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute((const void*)ssim_bwd_k<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr = true;
+    }
+    if (k == 11)
+        hipLaunchKernelGGL(ssim_bwd_k<11>, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), bwd_lds_k<11>(), (hipStream_t)s, x, y, h, w,
+                           make_win(win_host, k), c1, c2, wts, use_ssim, dcoarse, hc, wc, l1_coef, dx);
+    else
+        hipLaunchKernelGGL(ssim_bwd_kernel, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                           make_win(win_host, k), c1, c2, wts, use_ssim, dcoarse, hc, wc, l1_coef, dx);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
