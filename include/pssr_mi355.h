@@ -129,6 +129,10 @@ typedef struct pssr_conv_desc {
 } pssr_conv_desc;
 
 int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
+/* Tuning / test knob: which main loop pssr_conv2d uses for images >= 16x16.  0 (default): always the 128-pixel tiles; 1:
+ * the pipelined 256-pixel LDS-DMA loop when the grid fills the chip; 2: the pipelined loop whenever the shape allows.
+ * Returns the previous mode (any other argument only queries).  Also settable with the environment variable PSSR_IGEMM_V2. */
+int pssr_conv2d_pipeline_mode(int mode);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d.weight):
  *   dw[n][tap][k] = sum_pixels dy[p][n] * prologue(in)[p + tap][k]      (f32)

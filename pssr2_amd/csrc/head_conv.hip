@@ -76,18 +76,30 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bw[ks][nt] = wfrag_fwd(p, ks, nt, lane);
-    for (int g = wave; g < HGROUPS; g += 4) {
-        const int hp = g * 16 + (lane & 15);
+    // a wave owns halo groups wave, wave+4, ...: all of its loads are issued before the first MFMA (a constant trip count
+    // so that the loop unrolls; the activation stream is the only HBM traffic of this kernel)
+    constexpr int GPW = (HGROUPS + 3) / 4;
+    bf16x8 av[GPW][KS];
+    bool okv[GPW];
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+        const int hp = (wave + 4 * j) * 16 + (lane & 15);
         const int gy = ty0 + hp / HS - 1, gx = tx0 + hp % HS - 1;
-        const bool ok = hp < HPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const bf16_t* src = p.P + pix_index(img, ok ? gy : 0, ok ? gx : 0, p.H, p.W, p.blk) * p.p_cs + p.p_co + 8 * (lane >> 4);
+        okv[j] = hp < HPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bf16_t* src = p.P + pix_index(img, okv[j] ? gy : 0, okv[j] ? gx : 0, p.H, p.W, p.blk) * p.p_cs + p.p_co + 8 * (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[j][ks] = *(const bf16x8*)(src + ks * 32);
+    }
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+        const int g = wave + 4 * j;
+        if (g >= HGROUPS) continue;
         f32x4_t acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 a = *(const bf16x8*)(src + ks * 32);
-            if (!ok) a = zero_frag();
+            const bf16x8 a = okv[j] ? av[j][ks] : zero_frag();
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[ks][nt], acc[nt], 0, 0, 0);
         }
@@ -151,16 +163,26 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadArgs p) {
     __syncthreads();
     // coalesced write-out with the ReLU mask of the forward activation: 16-byte pieces, whole pixel rows per wave
     constexpr int PPP = C / 8;                             // pieces per pixel
-    for (int i = tid; i < 256 * PPP; i += 256) {
+    bf16x8 actv[PPP];
+    long qv[PPP];
+#pragma unroll
+    for (int u = 0; u < PPP; ++u) {                        // PPP trips of 256 pieces: all activation loads first
+        const int i = tid + u * 256;
         const int pix = i / PPP, pc = i % PPP;
         const int gy = ty0 + pix / TS, gx = tx0 + pix % TS;
-        if (gy >= p.H || gx >= p.W) continue;
-        const long q = pix_index(img, gy, gx, p.H, p.W, p.blk);
-        const bf16x8 act = *(const bf16x8*)(p.P + q * p.p_cs + p.p_co + pc * 8);
+        const bool ok = gy < p.H && gx < p.W;
+        qv[u] = ok ? pix_index(img, gy, gx, p.H, p.W, p.blk) : -1;
+        actv[u] = *(const bf16x8*)(p.P + (ok ? qv[u] : pix_index(img, ty0, tx0, p.H, p.W, p.blk)) * p.p_cs + p.p_co + pc * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < PPP; ++u) {
+        if (qv[u] < 0) continue;
+        const int i = tid + u * 256;
+        const int pix = i / PPP, pc = i % PPP;
         bf16x8 v = *(const bf16x8*)(O + pix * C + pc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (!((float)act[j] > 0.f)) v[j] = (bf16_t)0.f;
-        *(bf16x8*)(p.dP + q * p.dp_cs + p.dp_co + pc * 8) = v;
+        for (int j = 0; j < 8; ++j) if (!((float)actv[u][j] > 0.f)) v[j] = (bf16_t)0.f;
+        *(bf16x8*)(p.dP + qv[u] * p.dp_cs + p.dp_co + pc * 8) = v;
     }
 }
 
@@ -193,21 +215,34 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadArgs p, int n
         }
         __syncthreads();
         if (active) {
-            for (int pix = pl; pix < 256; pix += ppb) {
-                const int py = pix / TS, px = pix % TS;
-                const int gy = ty0 + py, gx = tx0 + px;
-                if (gy >= p.H || gx >= p.W) continue;
-                float v[4];
-                load4(p.P + pix_index(img, gy, gx, p.H, p.W, p.blk) * p.p_cs + p.p_co + cg * 4, v);
+            // 4 pixels per trip: the 4 (independent) global loads are issued before any arithmetic, so every thread keeps
+            // 4 x 8 bytes in flight instead of one (the kernel is a latency-bound stream otherwise)
+            for (int pix0 = pl; pix0 < 256; pix0 += 4 * ppb) {
+                float v[4][4];
+                int pyv[4], pxv[4];
+                bool okv[4];
 #pragma unroll
-                for (int co = 0; co < COUT; ++co)
+                for (int u = 0; u < 4; ++u) {
+                    const int pix = pix0 + u * ppb;
+                    pyv[u] = pix / TS; pxv[u] = pix % TS;
+                    const int gy = ty0 + pyv[u], gx = tx0 + pxv[u];
+                    okv[u] = pix < 256 && gy < p.H && gx < p.W;
+                    const long q = okv[u] ? pix_index(img, gy, gx, p.H, p.W, p.blk) : pix_index(img, ty0, tx0, p.H, p.W, p.blk);
+                    load4(p.P + q * p.p_cs + p.p_co + cg * 4, v[u]);
+                }
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        // dW[tap] += g[q - off(tap)] * P[q]
-                        const float gv = G[co * HPIX + (py + 2 - tap / 3) * HS + px + 2 - tap % 3];
+                for (int u = 0; u < 4; ++u) {
+                    if (!okv[u]) continue;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[co][tap][e] = fmaf(gv, v[e], acc[co][tap][e]);
-                    }
+                    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) {
+                            // dW[tap] += g[q - off(tap)] * P[q]
+                            const float gv = G[co * HPIX + (pyv[u] + 2 - tap / 3) * HS + pxv[u] + 2 - tap % 3];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[co][tap][e] = fmaf(gv, v[u][e], acc[co][tap][e]);
+                        }
+                }
             }
         }
     }

@@ -31,9 +31,26 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 2], ids=["default", "pipelined"])
+def pipeline_mode(request):
+    """Run a test under the default kernel selection and with the pipelined 256-pixel main loop forced on."""
+    from pssr2_amd import _lib as L
+    old = L.lib().pssr_conv2d_pipeline_mode(request.param)
+    yield request.param
+    L.lib().pssr_conv2d_pipeline_mode(old if old >= 0 else 0)
+
+
+CASES += [
+    (2, 48, 128, 32, 48, 3),     # >= 16x16: eligible for the pipelined loop (3 chunks, BN = 128)
+    (3, 16, 64, 16, 40, 3),      # BN = 64, partial tiles in x, one chunk
+    (2, 80, 192, 24, 24, 1),     # 1x1, odd chunk count (5), two N tiles, partial tiles
+    (1, 32, 72, 36, 20, 1),      # 1x1, BN = 128 with cout not a multiple of 32
+]
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_forward_and_dgrad(case, dt):
+def test_conv_forward_and_dgrad(case, dt, pipeline_mode):
     from pssr2_amd import ops, _lib as L
     n, cin, cout, h, w, ks = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -73,7 +90,7 @@ def test_conv_forward_and_dgrad(case, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_conv_fused_prologue_epilogues(dt):
+def test_conv_fused_prologue_epilogues(dt, pipeline_mode):
     from pssr2_amd import ops, _lib as L
     g = torch.Generator().manual_seed(3)
     n, cin, cout, h, w = 2, 32, 64, 16, 24
@@ -136,7 +153,7 @@ def test_conv_fused_prologue_epilogues(dt):
     np.testing.assert_allclose(s[cin:], (got.double() * xhat.double()).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=2e-3)
 
 
-def test_conv_two_sources_and_errors():
+def test_conv_two_sources_and_errors(pipeline_mode):
     from pssr2_amd import ops, _lib as L
     g = torch.Generator().manual_seed(5)
     n, h, w, c0, c1, cout = 2, 16, 16, 32, 1, 64
