@@ -154,6 +154,125 @@ __global__ void dwconv7_wgrad_kernel(Ref dy, Ref x, float* __restrict__ dw, int 
     }
 }
 
+// Row-segment variants (W % 8 == 0): a thread produces 8 consecutive x positions of 4 channels from a sliding window of
+// 14 inputs per kernel row held in registers: 98 + 49 loads per 8 outputs instead of 98 per output.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_seg_kernel(Ref in, const float* __restrict__ wp, const float* __restrict__ bias, MRef out,
+                                                          int n, int h, int w, int c, int accumulate) {
+    const int cg = c / 4, ws = w / 8;
+    const long total = (long)n * h * ws * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (i % cg) * 4;
+        long t = i / cg;
+        const int xs = (t % ws) * 8; t /= ws;
+        const int y = t % h;
+        const long img_base = (t / h) * h * w;
+        float acc[8][4];
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) load4(bias + c0, b4);
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] = b4[e];
+        for (int ky = 0; ky < 7; ++ky) {
+            const int sy = y + ky - 3;
+            if (sy < 0 || sy >= h) continue;
+            float v[14][4];
+            const long row = img_base + (long)sy * w;
+#pragma unroll
+            for (int j = 0; j < 14; ++j) {
+                const int sx = xs - 3 + j;
+                if (sx >= 0 && sx < w) load4(at<T>(in, row + sx, c0), v[j]);
+                else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float4 wv = *(const float4*)(wp + (ky * 7 + kx) * c + c0);
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    acc[o][0] = fmaf(v[o + kx][0], wv.x, acc[o][0]); acc[o][1] = fmaf(v[o + kx][1], wv.y, acc[o][1]);
+                    acc[o][2] = fmaf(v[o + kx][2], wv.z, acc[o][2]); acc[o][3] = fmaf(v[o + kx][3], wv.w, acc[o][3]);
+                }
+            }
+        }
+        const long prow = img_base + (long)y * w + xs;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (accumulate) {
+                float prev[4];
+                load4(at<T>(out, prow + o, c0), prev);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o][e] += prev[e];
+            }
+            store4(at<T>(out, prow + o, c0), acc[o]);
+        }
+    }
+}
+
+// blockIdx.y = ky; a thread keeps one channel group and walks row segments of 8 pixels
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_wgrad_seg_kernel(Ref dy, Ref x, float* __restrict__ dw, int n, int h, int w, int c) {
+    __shared__ float lds[TPB * 28];
+    const int cgc = c / 4, ws = w / 8;
+    const int ky = blockIdx.y;
+    const long nseg = (long)n * h * ws;
+    const int ppb = cgc <= TPB ? TPB / cgc : 1;
+    for (int cg0 = 0; cg0 < cgc; cg0 += TPB) {
+        const int cg = cg0 + (cgc <= TPB ? (int)threadIdx.x % cgc : (int)threadIdx.x);
+        const int pl = cgc <= TPB ? (int)threadIdx.x / cgc : 0;
+        const bool active = cg < cgc && pl < ppb;
+        float acc[7][4];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+        if (active) {
+            for (long sgi = (long)blockIdx.x * ppb + pl; sgi < nseg; sgi += (long)gridDim.x * ppb) {
+                long t = sgi;
+                const int xs = (t % ws) * 8; t /= ws;
+                const int y = t % h;
+                const long img_base = (t / h) * h * w;
+                const int sy = y + ky - 3;
+                if (sy < 0 || sy >= h) continue;
+                float g[8][4], v[14][4];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) load4(at<T>(dy, img_base + (long)y * w + xs + o, cg * 4), g[o]);
+#pragma unroll
+                for (int j = 0; j < 14; ++j) {
+                    const int sx = xs - 3 + j;
+                    if (sx >= 0 && sx < w) load4(at<T>(x, img_base + (long)sy * w + sx, cg * 4), v[j]);
+                    else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
+                }
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[kx][e] = fmaf(g[o][e], v[o + kx][e], acc[kx][e]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[threadIdx.x * 28 + k * 4 + e] = active ? acc[k][e] : 0.f;
+        __syncthreads();
+        if (cgc <= TPB) {
+            if ((int)threadIdx.x < cgc) {
+                for (int k = 0; k < 7; ++k)
+                    for (int e = 0; e < 4; ++e) {
+                        float t = 0.f;
+                        for (int q = 0; q < ppb; ++q) t += lds[(q * cgc + threadIdx.x) * 28 + k * 4 + e];
+                        atomicAdd(dw + (long)(threadIdx.x * 4 + e) * 49 + ky * 7 + k, t);
+                    }
+            }
+        } else if (active) {
+            for (int k = 0; k < 7; ++k)
+                for (int e = 0; e < 4; ++e) atomicAdd(dw + (long)(cg * 4 + e) * 49 + ky * 7 + k, acc[k][e]);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm2d: one wave per pixel, lane l holds channel groups l, l+64, ...  (C <= 256*LN_MAXIT)
 constexpr int LN_MAXIT = 8;
@@ -444,8 +563,13 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
     PSSR_CHECK(in && w_packed && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7: bad args");
     CHECK_REF("dwconv7 in", in_cs, in_co, c); CHECK_REF("dwconv7 out", out_cs, out_co, c);
     const long total = (long)n * h * w * (c / 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_kernel<T>, dim3(grid1d(total, 1 << 20)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co}, w_packed, bias,
-                                         MRef{out, out_cs, out_co}, n, h, w, c, accumulate));
+    if (w % 8 == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_seg_kernel<T>, dim3(grid1d(total / 8, 1 << 20)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co},
+                                             w_packed, bias, MRef{out, out_cs, out_co}, n, h, w, c, accumulate));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_kernel<T>, dim3(grid1d(total, 1 << 20)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co}, w_packed,
+                                             bias, MRef{out, out_cs, out_co}, n, h, w, c, accumulate));
+    }
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -458,8 +582,16 @@ int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int 
     long gx = ((long)n * h * w + ppb - 1) / ppb / 16;       // >= 16 pixels per thread before the atomics
     if (gx < 1) gx = 1;
     if (gx > 96) gx = 96;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_kernel<T>, dim3((unsigned)gx, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
-                                         Ref{x, x_cs, x_co}, dw, n, h, w, c));
+    if (w % 8 == 0) {
+        long gs = ((long)n * h * (w / 8) + ppb - 1) / ppb / 4;       // >= 4 row segments per thread before the atomics
+        if (gs < 1) gs = 1;
+        if (gs > 146) gs = 146;                                      // x 7 kernel rows ~ 4 workgroups per CU
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_seg_kernel<T>, dim3((unsigned)gs, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
+                                             Ref{x, x_cs, x_co}, dw, n, h, w, c));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_kernel<T>, dim3((unsigned)gx, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
+                                             Ref{x, x_cs, x_co}, dw, n, h, w, c));
+    }
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

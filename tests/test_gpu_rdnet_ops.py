@@ -42,7 +42,7 @@ def test_patchify():
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(2, 24, 9, 13), (1, 264, 16, 16), (3, 8, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 24, 9, 13), (1, 264, 16, 16), (3, 8, 4, 4), (2, 40, 6, 24), (1, 1040, 8, 8)])
 def test_dwconv7(shape, dt):
     from pssr2_amd import ops
     n, c, h, w = shape
