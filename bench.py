@@ -113,7 +113,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--lr-res", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
+                    help="fp16: a static loss scale of 1024 stands in for train_paired's dynamic LossScaler (no host sync in the captured step)")
+    ap.add_argument("--channels", type=int, default=1, help="image channels / frames (BASELINE config 4 uses 3)")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--model", default="resunet", choices=["resunet", "rdresunet"],
                     help="resunet = BASELINE.json configs[1] (default, the metric's config); rdresunet = configs[2] (RDNet encoder)")
@@ -137,14 +139,15 @@ def main():
     import numpy as np
 
     torch.manual_seed(0)
-    model = (ResUNet() if args.model == "resunet" else RDResUNet()).to(dev)
-    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = (ResUNet(channels=args.channels) if args.model == "resunet" else RDResUNet(channels=args.channels)).to(dev)
+    model.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[args.dtype]
+    loss_scale = 1024.0 if args.dtype == "fp16" else 1.0
     D.broadcast_module(model)
     opt = FusedAdamW(model.parameters(), lr=1e-3)
-    loss_fn = SSIMLoss(mix=0.8)
+    loss_fn = SSIMLoss(channels=args.channels, mix=0.8)
     hr_res = args.lr_res * 4
     pool_n = 8                                           # distinct synthetic EM tiles per rank (tiled to the batch)
-    pool = np.stack([synthetic_em_tile(rank * 100003 + i, hr_res) for i in range(pool_n)])
+    pool = np.stack([synthetic_em_tile(rank * 100003 + i, hr_res, channels=args.channels) for i in range(pool_n)])
     pool = torch.from_numpy(pool).to(dev)                # uint8 [pool, 1, HR, HR], resident in HBM
     from pssr2_amd import ops
     use_graph = not args.no_graph
@@ -169,7 +172,7 @@ def main():
         hr, lr = next_batch()
         hr_hat = model(lr)
         loss = loss_fn(hr_hat / 255, hr / 255)
-        loss.backward()
+        (loss * loss_scale if loss_scale != 1.0 else loss).backward()
         return loss
 
     def reduce_and_update():
@@ -177,7 +180,7 @@ def main():
             flat = model._engine._flat_grad
             torch.distributed.all_reduce(flat)
             flat.mul_(1.0 / world)
-        opt.step()
+        opt.step(grad_scale=1.0 / loss_scale)
         opt.zero_grad()
 
     def infer_body():
@@ -230,7 +233,7 @@ def main():
             def fn(s):
                 fwd_bwd()
                 if world > 1:
-                    opt.step(), opt.zero_grad()
+                    opt.step(grad_scale=1.0 / loss_scale), opt.zero_grad()
                 else:
                     reduce_and_update()
     else:
@@ -285,7 +288,7 @@ def main():
             "value": round(tiles_per_s, 2), "unit": "HR tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'ResUNet' if args.model == 'resunet' else 'RDResUNet'} 1-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
+            "config": {"workload": f"{'ResUNet' if args.model == 'resunet' else 'RDResUNet'} {args.channels}-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
                                    f"{'AdditiveGaussian(13)' if args.crappifier == 'gaussian' else 'Poisson()'} device crappifier, MS-SSIM+L1 (mix .8), AdamW",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager"},

@@ -11,8 +11,9 @@
  *     pssr_last_error() returns a thread-local message for the last failure;
  *   - activations are NHWC ("pixel-major") with an explicit channel stride so that an op can read
  *     or write a channel slice of a wider buffer (this is how torch.cat is elided);
- *   - dtype of activations / packed weights: PSSR_F32 (exact-f32 MFMA path, parity) or
- *     PSSR_BF16 (bf16 storage, f32 accumulate).  Parameters, statistics and gradients are f32/f64.
+ *   - dtype of activations / packed weights: PSSR_F32 (exact-f32 MFMA path, parity), PSSR_BF16 or PSSR_F16
+ *     (16-bit storage, f32 accumulate; fp16 needs loss scaling by the caller).  Parameters, statistics and
+ *     gradients are f32/f64.
  */
 #ifndef PSSR_MI355_H
 #define PSSR_MI355_H
@@ -25,7 +26,7 @@ extern "C" {
 
 typedef void* pssr_stream_t; /* hipStream_t */
 
-enum { PSSR_F32 = 0, PSSR_BF16 = 1 };
+enum { PSSR_F32 = 0, PSSR_BF16 = 1, PSSR_F16 = 2 };
 
 enum {
     PSSR_OK = 0,

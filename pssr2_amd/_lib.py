@@ -12,7 +12,7 @@ from pathlib import Path
 _LIB_PATH = Path(__file__).resolve().parent / "libpssr_mi355.so"
 _lib = None
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 PRO_NONE, PRO_BN_RELU, PRO_GELU = 0, 1, 2
 EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 FLAG_RELU, FLAG_STATS = 1, 2

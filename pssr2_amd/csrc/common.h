@@ -6,6 +6,9 @@
 #include "../../include/pssr_mi355.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -61,6 +64,28 @@ template <> struct TT<bf16_t> {
     }
 };
 
+template <> struct TT<f16_t> {      // fp16 storage, f32 accumulate (config "fp16": needs loss scaling on the host side)
+    static constexpr int EPS = 8;
+    static constexpr int KCH = 16;
+    typedef f16x8 frag_t;
+    static __device__ __forceinline__ void unpack(const u32x4& raw, float* f) {
+        const f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* f) {
+        f16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (f16_t)f[i];
+        return __builtin_bit_cast(u32x4, v);
+    }
+    static __device__ __forceinline__ float round(float v) { return (float)(f16_t)v; }
+    // one v_mfma_f32_32x32x16_f16
+    static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
@@ -71,6 +96,18 @@ __device__ __forceinline__ void store4(bf16_t* p, const float* v) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) cv.v[i] = (bf16_t)v[i];
     *(uint2*)p = cv.u;
+}
+__device__ __forceinline__ void store4(f16_t* p, const float* v) {
+    union { f16x4 v; uint2 u; } cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv.v[i] = (f16_t)v[i];
+    *(uint2*)p = cv.u;
+}
+__device__ __forceinline__ void load4(const f16_t* p, float* v) {
+    union { f16x4 v; uint2 u; } cv;
+    cv.u = *(const uint2*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)cv.v[i];
 }
 __device__ __forceinline__ void load4(const float* p, float* v) {
     float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;

@@ -708,9 +708,9 @@ extern "C" int pssr_conv2d_pipeline_mode(int mode) {
 
 extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     PSSR_CHECK(d != nullptr, PSSR_ERR_ARG, "conv2d: null desc");
-    PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16, PSSR_ERR_ARG, "conv2d: bad dtype %d", d->dtype);
-    const int kch = d->dtype == PSSR_BF16 ? 16 : 8;
-    const int esz = d->dtype == PSSR_BF16 ? 2 : 4;
+    PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16 || d->dtype == PSSR_F16, PSSR_ERR_ARG, "conv2d: bad dtype %d", d->dtype);
+    const int kch = d->dtype == PSSR_F32 ? 8 : 16;
+    const int esz = d->dtype == PSSR_F32 ? 4 : 2;
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "conv2d: bad shape %dx%dx%d", d->n, d->h, d->w);
     PSSR_CHECK(d->in0 && d->w0 && d->out, PSSR_ERR_ARG, "conv2d: null pointer");
     PSSR_CHECK(d->cin0 > 0 && d->cin0 % kch == 0, PSSR_ERR_ARG, "conv2d: cin0=%d must be a positive multiple of %d", d->cin0, kch);
@@ -760,5 +760,5 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     a.out_scale = d->out_scale; a.out_shift = d->out_shift;
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : launch_bn<float>(a, s);
+    return d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : d->dtype == PSSR_F16 ? launch_bn<f16_t>(a, s) : launch_bn<float>(a, s);
 }

@@ -32,8 +32,7 @@ template <> struct WGeo<1> { static constexpr int TWL = 3, THL = 3; };
 template <> struct WGeo<2> { static constexpr int TWL = 2, THL = 2; };
 
 // fragment fetch: 8 (bf16) / 4 (f32) reduction rows for one 32-wide channel sub-tile
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
+struct Frag16 {      // any 16-bit element type
     static constexpr int KP = 16;   // pixels per k-step
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     // `rowaddr0/1`: LDS byte address of (this lane's row q, its 4 columns) for reduction rows q and q+4
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && GEO < 2) ? 2 : 1) void conv
                 const int g = lane >> 4, i = lane & 15, q = i >> 2, pcol = i & 3;
                 const int colb = ((g & 1) * 16 + pcol * 4) * 2;
                 const int m0 = s * 16 + (g >> 1) * 8 + q;
-                af = Frag<bf16_t>::load(dy_img + m0 * ROWB + colb, dy_img + (m0 + 4) * ROWB + colb);
+                af = Frag16::load(dy_img + m0 * ROWB + colb, dy_img + (m0 + 4) * ROWB + colb);
 #pragma unroll
                 for (int rd = 0; rd < 2; ++rd) {
                     const int m = m0 + 4 * rd;
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && GEO < 2) ? 2 : 1) void conv
                 const int toff = (ky * HW2 + kx) * ROWB;
                 u32x4 bf;
                 if constexpr (sizeof(T) == 2) {
-                    bf = Frag<bf16_t>::load(ah_img + hb[0] + toff, ah_img + hb[1] + toff);
+                    bf = Frag16::load(ah_img + hb[0] + toff, ah_img + hb[1] + toff);
                 } else {
                     float b4[4];
                     if constexpr (TW >= 4) {
@@ -334,13 +333,13 @@ extern "C" int pssr_conv2d_wgrad_parts(const pssr_wgrad_desc* d) {
 
 static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* query) {
     PSSR_CHECK(d != nullptr, PSSR_ERR_ARG, "wgrad: null desc");
-    PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16, PSSR_ERR_ARG, "wgrad: bad dtype %d", d->dtype);
-    const int esz = d->dtype == PSSR_BF16 ? 2 : 4;
+    PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16 || d->dtype == PSSR_F16, PSSR_ERR_ARG, "wgrad: bad dtype %d", d->dtype);
+    const int esz = d->dtype == PSSR_F32 ? 4 : 2;
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "wgrad: bad shape");
     PSSR_CHECK(query != nullptr || (d->dy && d->in && d->dw), PSSR_ERR_ARG, "wgrad: null pointer");
     PSSR_CHECK(d->dw_parts >= 0, PSSR_ERR_ARG, "wgrad: dw_parts=%d", d->dw_parts);
     PSSR_CHECK(d->taps == 9 || d->taps == 1, PSSR_ERR_ARG, "wgrad: taps=%d", d->taps);
-    PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % (d->dtype == PSSR_BF16 ? 16 : 8) == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of the K-chunk", d->cin_pad);
+    PSSR_CHECK(d->cin_pad > 0 && d->cin_pad % (d->dtype == PSSR_F32 ? 8 : 16) == 0, PSSR_ERR_ARG, "wgrad: cin_pad=%d must be a multiple of the K-chunk", d->cin_pad);
     PSSR_CHECK(d->cout > 0 && (d->cout * esz) % 16 == 0, PSSR_ERR_ARG, "wgrad: cout=%d must fill whole 16-byte slots", d->cout);
     PSSR_CHECK((d->dy_cstride * esz) % 16 == 0 && (d->dy_coff * esz) % 16 == 0 && d->dy_coff + d->cout <= d->dy_cstride, PSSR_ERR_ARG, "wgrad: dy stride/offset");
     PSSR_CHECK((d->in_cstride * esz) % 16 == 0 && (d->in_coff * esz) % 16 == 0 && d->in_coff + d->cin_pad <= d->in_cstride, PSSR_ERR_ARG, "wgrad: in stride/offset");
@@ -354,5 +353,6 @@ static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* quer
     a.taps = d->taps; a.prologue = d->prologue; a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
     a.dw = d->dw; a.parts = d->dw_parts; a.part_stride = 0;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s, query) : launch_shape<float>(a, s, query);
+    return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s, query)
+         : d->dtype == PSSR_F16 ? launch_shape<f16_t>(a, s, query) : launch_shape<float>(a, s, query);
 }

@@ -89,6 +89,7 @@ __global__ void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
     const pssr_pack_item it = items[blockIdx.y];
     const PackMap m{it.cout, it.cin, it.ks, it.ci_begin, it.ci_count, it.mode, it.mode >= 2 ? 1 : it.ks * it.ks, it.n_perm, it.center};
     if (it.dtype == PSSR_BF16) pack_item<bf16_t>(it, m);
+    else if (it.dtype == PSSR_F16) pack_item<f16_t>(it, m);
     else pack_item<float>(it, m);
 }
 
@@ -123,7 +124,7 @@ __global__ void unpack_zero_kernel(float* __restrict__ dw, PackMap m, int k_pad,
 }  // namespace
 
 extern "C" int64_t pssr_packed_weight_bytes(int taps, int k_pad, int n_pad, int dtype) {
-    return (int64_t)taps * k_pad * n_pad * (dtype == PSSR_BF16 ? 2 : 4);
+    return (int64_t)taps * k_pad * n_pad * (dtype == PSSR_F32 ? 4 : 2);
 }
 
 extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int cin, int ks, int ci_begin, int ci_count,
@@ -143,6 +144,8 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == PSSR_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, m, k_pad, n_pad, total);
+    else if (dtype == PSSR_F16)
+        hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (f16_t*)packed, m, k_pad, n_pad, total);
     else if (dtype == PSSR_F32)
         hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, m, k_pad, n_pad, total);
     else

@@ -532,6 +532,7 @@ __global__ void ese_bwd_kernel(int stage, const float* __restrict__ A, const flo
 #define DISPATCH_T(dtype, CALL)                                             \
     do {                                                                    \
         if ((dtype) == PSSR_BF16) { using T = bf16_t; CALL; }               \
+        else if ((dtype) == PSSR_F16) { using T = f16_t; CALL; }            \
         else if ((dtype) == PSSR_F32) { using T = float; CALL; }            \
         else { pssr_set_error("bad dtype %d", (dtype)); return PSSR_ERR_ARG; } \
     } while (0)

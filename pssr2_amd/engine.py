@@ -224,11 +224,11 @@ class Engine:
         return c
 
     def _check_supported(self, dtype_code, h, w, train):
-        kch = 16 if dtype_code == L.BF16 else 8
+        kch = 8 if dtype_code == L.F32 else 16
         for i, hc in enumerate(self.hidden):
             if hc % kch:
                 raise ValueError(f"hidden[{i}]={hc}: the MI355X path needs channel counts that are multiples of {kch} "
-                                 f"for compute dtype {'bf16' if dtype_code == L.BF16 else 'f32'}")
+                                 f"for compute dtype {ops.TORCH_DTYPE[dtype_code]}")
             if i and hc % 16:
                 raise ValueError(f"hidden[{i}]={hc} must be a multiple of 16 (pixel-shuffle slice alignment)")
         if h % (1 << (self.L - 1)) or w % (1 << (self.L - 1)):
@@ -485,7 +485,7 @@ class Engine:
     def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,
                n_perm=None, pro=None, dy_blk=0, in_blk=0, hh, ww, center=False, dy_view_c=None):
         code = p.code
-        esz = 2 if code == L.BF16 else 4
+        esz = 4 if code == L.F32 else 2
         co_eff = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
         dwp = ops.conv2d_wgrad_parts(dy, co_eff, src, cin_pad, taps, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
                                      pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)

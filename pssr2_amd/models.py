@@ -79,8 +79,8 @@ class ResUNet(nn.Module):
         (pssr/models/resunet.py:8-17).  ``dilations`` / ``pool_sizes`` (the atrous / PSP variants,
         SURVEY.md §8f-4) are validated like the reference but not implemented on the MI355X path.
 
-        Extra attribute: ``compute_dtype`` (torch.float32 — exact-f32 MFMA, default — or
-        torch.bfloat16 — bf16 storage / f32 accumulate).
+        Extra attribute: ``compute_dtype``: torch.float32 (exact-f32 MFMA, default), torch.bfloat16 or torch.float16
+        (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16).
         """
         super().__init__()
         channels = _force_list(channels)
@@ -248,7 +248,7 @@ class RDResUNet(nn.Module):
         ``state_dict`` as the reference (pssr/models/rdresunet.py:9-102).  ``dilations`` / ``pool_sizes`` are validated like
         the reference but not implemented on the MI355X path; ``drop_rate`` is a no-op upstream too (_rdnet.py:161,168-175).
 
-        Extra attribute: ``compute_dtype`` (torch.float32 — exact-f32 MFMA — or torch.bfloat16).
+        Extra attribute: ``compute_dtype`` (torch.float32 — exact-f32 MFMA — torch.bfloat16 or torch.float16).
         """
         super().__init__()
         channels = _force_list(channels)

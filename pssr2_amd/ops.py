@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 
-TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16}
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -19,7 +19,9 @@ def dtype_code(dt: torch.dtype) -> int:
         return L.F32
     if dt == torch.bfloat16:
         return L.BF16
-    raise ValueError(f"unsupported compute dtype {dt}; use torch.float32 or torch.bfloat16")
+    if dt == torch.float16:
+        return L.F16
+    raise ValueError(f"unsupported compute dtype {dt}; use torch.float32, torch.bfloat16 or torch.float16")
 
 
 def pad_to(v: int, m: int) -> int:
@@ -383,7 +385,7 @@ def ese_bwd(A, gate, u, gamma, s_mean, w_fc, hw, du, dgamma, db_fc, dw_fc, add):
 # ----------------------------------------------------------------------------------------------
 # Reconstruction.conv for C_out <= 3 (csrc/head_conv.hip), bf16 storage
 def head_conv_supported(dtype, cin, cout):
-    return dtype == L.BF16 and 1 <= cout <= 3 and cin % 32 == 0 and 32 <= cin <= 128
+    return dtype in (L.BF16, L.F16) and 1 <= cout <= 3 and cin % 32 == 0 and 32 <= cin <= 128
 
 
 def head_conv_fwd(act, blk, weight, bias, out, n, h, w, cin, cout, out_scale, out_shift, dtype, act_coff=0):

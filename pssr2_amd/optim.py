@@ -86,3 +86,43 @@ class FusedAdamW(torch.optim.Optimizer):
         """Flat gradient buffer of a group (the engine writes into it directly when it can)."""
         st = self._flat.get(gi)
         return None if st is None else st["grad"]
+
+
+class LossScaler:
+    """Dynamic loss scaling for ``compute_dtype = torch.float16`` (BASELINE config 4).  The reference trains in fp32 only
+    (no AMP anywhere in pssr/), so this has no upstream counterpart: activations and their gradients are stored in fp16 on
+    the MI355X path, hence the loss is multiplied by ``scale`` before ``backward`` and the (f32) parameter gradients are
+    divided by it inside the optimizer step; a step whose gradients are not finite is skipped and the scale halved, and
+    the scale doubles after ``growth_interval`` good steps (the torch.amp.GradScaler policy)."""
+
+    def __init__(self, init_scale=2.0 ** 12, growth_factor=2.0, backoff_factor=0.5, growth_interval=200):
+        self.scale_value, self.growth, self.backoff, self.interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self.good_steps, self.skipped = 0, 0
+
+    def scale(self, loss):
+        return loss * self.scale_value
+
+    def step(self, optim, params):
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return False
+        base = getattr(grads[0], "_base", None)
+        if base is not None and all(getattr(g, "_base", None) is base for g in grads):
+            finite = bool(torch.isfinite(base).all())           # the engine's flat gradient buffer: one pass
+        else:
+            finite = all(bool(torch.isfinite(g).all()) for g in grads)
+        if finite:
+            if isinstance(optim, FusedAdamW):
+                optim.step(grad_scale=1.0 / self.scale_value)
+            else:
+                for g in ([base] if base is not None and all(getattr(g, "_base", None) is base for g in grads) else grads):
+                    g.mul_(1.0 / self.scale_value)
+                optim.step()
+            self.good_steps += 1
+            if self.good_steps % self.interval == 0:
+                self.scale_value *= self.growth
+        else:
+            self.skipped += 1
+            self.good_steps = 0
+            self.scale_value *= self.backoff
+        return finite

@@ -66,9 +66,9 @@ class RDEngine(Engine):
 
     def _check_supported_rd(self, code, h, w, train):
         enc, m = self.model.encoder, self.model
-        kch = 16 if code == L.BF16 else 8
-        g_align = 8 if code == L.BF16 else 4
-        name = "bf16" if code == L.BF16 else "f32"
+        kch = 8 if code == L.F32 else 16
+        g_align = 4 if code == L.F32 else 8
+        name = str(ops.TORCH_DTYPE[code])
         if enc.ds_blocks[0]:
             raise ValueError("ds_blocks[0] must be False (RDNet's first stage has no transition, pssr/models/_rdnet.py:54)")
         if h % (self.ps << (self.n_levels - 1)) or w % (self.ps << (self.n_levels - 1)):
@@ -81,7 +81,7 @@ class RDEngine(Engine):
         for k, hc in enumerate(self.hidden):
             if hc % kch:
                 raise ValueError(f"hidden[{k}]={hc}: the MI355X path needs channel counts that are multiples of {kch} for compute dtype {name}")
-            if (hc // m.ratios[k + 1] ** 2) % (8 if code == L.BF16 else 4):
+            if (hc // m.ratios[k + 1] ** 2) % (4 if code == L.F32 else 8):
                 raise ValueError(f"hidden[{k}]={hc} / {m.ratios[k + 1]}^2 must keep the skip slice 16-byte aligned")
         if self.h0 % kch:
             raise ValueError(f"head width hidden[-1]/patch_size^2 = {self.h0} must be a multiple of {kch} for compute dtype {name}")
@@ -258,7 +258,7 @@ class RDEngine(Engine):
 
     def _wgrad1x1(self, p, grads, conv_module, dy, cout, dy_coff, src, cin_pad, hh, ww, *, mode=0, gelu_in=False):
         code = p.code
-        esz = 2 if code == L.BF16 else 4
+        esz = 4 if code == L.F32 else 2
         rows = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
         dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
         w = conv_module.weight

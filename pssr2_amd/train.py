@@ -68,6 +68,12 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
         if engine is not None and engine.reducer is None:
             engine.attach_reducer()
 
+    # fp16 storage (model.compute_dtype = torch.float16) needs loss scaling; f32 / bf16 do not
+    scaler = None
+    if getattr(model, "compute_dtype", None) == torch.float16:
+        from .optim import LossScaler
+        scaler = LossScaler()
+
     train_losses, val_losses = [], []
     for epoch in range(epochs):
         model.train()
@@ -87,10 +93,13 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
                 hr_hat = torch.clamp(hr_hat, 0, image_range)
             loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
                 else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
-            loss.backward()
+            (scaler.scale(loss) if scaler is not None else loss).backward()
             if world > 1 and engine is None:
                 D.allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
-            optim.step()
+            if scaler is not None:
+                scaler.step(optim, list(model.parameters()))
+            else:
+                optim.step()
             optim.zero_grad()
 
             if batch_idx % log_frequency == 0 or batch_idx == len(progress) - 1:

@@ -21,11 +21,12 @@ def _unblocked(t, blk):
     return t.float().cpu().reshape(n, h // r, w // r, r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h, w, c).permute(0, 3, 1, 2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 64, 1, 48, 80, 2), (1, 32, 3, 40, 24, 2), (3, 64, 2, 16, 16, 0), (1, 96, 1, 36, 20, 1)])
-def test_head_conv(case):
+def test_head_conv(case, dt):
     from pssr2_amd import ops, _lib as L
     n, cin, cout, h, w, blk = case
-    dt = torch.bfloat16
+    code = ops.dtype_code(dt)
     g = torch.Generator().manual_seed(cin + cout)
     act = F.relu(torch.randn(n, cin, h, w, generator=g)).to(dt).float().requires_grad_(True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
@@ -34,19 +35,19 @@ def test_head_conv(case):
     ref = (F.conv2d(act, wq, b, padding=1)) * 128 + 128
     dout = torch.randn(ref.shape, generator=g)
     ref.backward(dout)
-    assert ops.head_conv_supported(L.BF16, cin, cout)
+    assert ops.head_conv_supported(code, cin, cout)
     ad = _blocked(act.detach(), blk, dt)
     out = torch.empty(n, cout, h, w, device="cuda")
-    ops.head_conv_fwd(ad, blk, wt.cuda().contiguous(), b.cuda(), out, n, h, w, cin, cout, 128.0, 128.0, L.BF16)
+    ops.head_conv_fwd(ad, blk, wt.cuda().contiguous(), b.cuda(), out, n, h, w, cin, cout, 128.0, 128.0, code)
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=2e-3, atol=2e-2 * 128 * ref.detach().sub(128).abs().max().item() / 128)
     # dgrad with the ReLU mask of the activation
     da = torch.full_like(ad, 7.0)
-    ops.head_conv_dgrad(dout.cuda(), 128.0, wt.cuda().contiguous(), ad, da, blk, n, h, w, cin, cout, L.BF16)
+    ops.head_conv_dgrad(dout.cuda(), 128.0, wt.cuda().contiguous(), ad, da, blk, n, h, w, cin, cout, code)
     want = act.grad * (act.detach() > 0)
     got = _unblocked(da, blk)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=3e-2, atol=2e-2 * want.abs().max().item())
     # wgrad, accumulated into an existing gradient
     base = torch.randn(cout, cin, 3, 3, generator=g)
     dw = base.clone().cuda()
-    ops.head_conv_wgrad(dout.cuda(), 128.0, ad, blk, dw, n, h, w, cin, cout, L.BF16)
+    ops.head_conv_wgrad(dout.cuda(), 128.0, ad, blk, dw, n, h, w, cin, cout, code)
     np.testing.assert_allclose((dw.cpu() - base).numpy(), wq.grad.numpy(), rtol=1e-3, atol=1e-3 * wq.grad.abs().max().item())

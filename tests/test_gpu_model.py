@@ -139,3 +139,58 @@ def test_default_model_vs_oracle_eval():
     assert abs(_psnr(y, hr) - _psnr(ref, hr)) <= 1e-3
     with pytest.raises(RuntimeError, match="MI355X"):
         model(x)          # CPU tensor: no fallback
+
+
+def test_fp16_three_channel_vs_oracle():
+    """BASELINE config 4 in miniature: ResUNet 3-ch, MS-SSIM + L1 with the depthwise L1 window, fp16 storage with loss
+    scaling.  Yardstick: an f64 evaluation of the oracle graph (forward within fp16 storage error, gradient direction)."""
+    from oracle import loss_ref as LR
+    from oracle import model_ref as M
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW, LossScaler
+    from pssr2_amd.util import SSIMLoss
+    sd0 = M.make_state_dict(channels=(3, 3), hidden=(16, 32, 64), seed=4)
+    model = ResUNet(channels=3, hidden=[16, 32, 64])
+    model.load_state_dict(sd0)
+    model.cuda()
+    model.compute_dtype = torch.float16
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 48, 48, generator=g) * 255
+    hr = torch.rand(2, 3, 192, 192, generator=g) * 255
+    model.eval()
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+        ref, _ = M.resunet_forward(x, sd0, 3, 3, 4, train=False)
+    assert (y - ref).abs().max() / ref.abs().max() < 0.02            # fp16 has 3 more mantissa bits than bf16
+    model.train()
+    loss_fn = SSIMLoss(channels=3, mix=0.8)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    scaler = LossScaler(init_scale=2.0 ** 10)
+    out = model(x.cuda())
+    loss = loss_fn(out / 255, hr.cuda() / 255)
+    scaler.scale(loss).backward()
+    grads = {n: p.grad.detach().clone().cpu().double() / scaler.scale_value for n, p in model.named_parameters()}
+    p64 = {k: (v.double().requires_grad_(True) if "running" not in k else v.double()) if v.dtype.is_floating_point else v for k, v in sd0.items()}
+    y64, _ = M.resunet_forward(x.double(), p64, 3, 3, 4, train=True)
+    l64 = LR.ssim_loss(y64 / 255, hr.double() / 255, mix=0.8)
+    assert abs(loss.item() - l64.item()) < 2e-3
+    l64.backward()
+
+    def cos(a, b):
+        a, b = a.flatten(), b.flatten()
+        return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+    low = [(n, cos(grads[n], p64[n].grad)) for n in grads if p64[n].grad.abs().max() > 1e-9 and cos(grads[n], p64[n].grad) < 0.9]     # 16-bit storage on an untrained, ReLU-mask-heavy net (cf. test_bf16_close_to_f32)
+    assert not low, low
+    before = [p.detach().clone() for p in model.parameters()]
+    assert scaler.step(opt, list(model.parameters())) is True        # finite gradients: the step is taken, unscaled
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, model.parameters()))
+    assert changed > 0.9 * len(before)
+    # an overflowing backward is skipped and halves the scale
+    opt.zero_grad()
+    out = model(x.cuda())
+    (loss_fn(out / 255, hr.cuda() / 255) * float("inf")).backward()
+    s0 = scaler.scale_value
+    before = [p.detach().clone() for p in model.parameters()]
+    assert scaler.step(opt, list(model.parameters())) is False and scaler.scale_value == s0 / 2
+    assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
