@@ -87,7 +87,7 @@ class ConvTimer:
                     gflop_per_launch=tot_fl / len(ms) / 1e9)
 
 
-def cpu_baseline(batch=2, lr_res=128):
+def cpu_baseline(batch=4, lr_res=128):
     """The oracle (CPU restatement, torch fp32) doing the same training step on a bounded sample."""
     from oracle import loss_ref, model_ref
     torch.manual_seed(0)
@@ -116,7 +116,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
                     help="fp16: a static loss scale of 1024 stands in for train_paired's dynamic LossScaler (no host sync in the captured step)")
     ap.add_argument("--channels", type=int, default=1, help="image channels / frames (BASELINE config 4 uses 3)")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "sheet"],
+                    help="sheet: BASELINE config 5 end to end on the device (4096^2 LR sheet -> 128^2 tiles, overlap 32 -> predict -> "
+                         "uint8 -> overlap-averaged 16384^2-class sheet), one step = one sheet")
     ap.add_argument("--model", default="resunet", choices=["resunet", "rdresunet"],
                     help="resunet = BASELINE.json configs[1] (default, the metric's config); rdresunet = configs[2] (RDNet encoder)")
     ap.add_argument("--crappifier", default="gaussian", choices=["gaussian", "poisson"])
@@ -125,9 +127,16 @@ def main():
     args = ap.parse_args()
 
     from pssr2_amd import distributed as D
-    rank, world, local = D.init_from_env()
+    # rehearsal knobs (NOT used by the driver): run several ranks on ONE card over gloo to exercise the data-parallel code
+    # path on a 1-GPU box, e.g.  PSSR_BENCH_BACKEND=gloo PSSR_BENCH_FORCE_DEVICE=0 python -m torch.distributed.run ...
+    force_dev = os.environ.get("PSSR_BENCH_FORCE_DEVICE")
+    if force_dev is not None:
+        torch.cuda.set_device(int(force_dev))
+    rank, world, local = D.init_from_env(os.environ.get("PSSR_BENCH_BACKEND"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if force_dev is not None:
+        local = int(force_dev)
     torch.cuda.set_device(local if world > 1 else 0)
     dev = torch.device("cuda", local if world > 1 else 0)
 
@@ -175,13 +184,13 @@ def main():
         (loss * loss_scale if loss_scale != 1.0 else loss).backward()
         return loss
 
-    def reduce_and_update():
+    def reduce_and_update(zero=True):
         if world > 1:
             flat = model._engine._flat_grad
-            torch.distributed.all_reduce(flat)
-            flat.mul_(1.0 / world)
-        opt.step(grad_scale=1.0 / loss_scale)
-        opt.zero_grad()
+            torch.distributed.all_reduce(flat)        # SUM; the mean's 1/world is folded into the optimizer's gradient scale
+        opt.step(grad_scale=1.0 / (loss_scale * world))
+        if zero:
+            opt.zero_grad()
 
     def infer_body():
         _, lr = next_batch()
@@ -208,7 +217,8 @@ def main():
 
     if args.mode == "train":
         model.train()
-        if use_graph and world == 1:
+        split_graph = world > 1 or os.environ.get("PSSR_BENCH_SPLIT_GRAPH") == "1"      # rehearsal of the N>1 structure on one rank
+        if use_graph and not split_graph:
             def whole():
                 fwd_bwd()
                 reduce_and_update()
@@ -221,11 +231,18 @@ def main():
                 reduce_and_update()
             for _ in range(2):
                 eager_step()
-            capture("fwd_bwd", fwd_bwd)
+            def fwd_bwd_fresh():
+                opt.zero_grad()               # Python-only (sets .grad = None): the engine then publishes views of its flat buffer
+                fwd_bwd()
+            capture("fwd_bwd", fwd_bwd_fresh)
+            # Replays run no Python, so the .grad views published during capture must stay in place: no zero_grad()
+            # between steps (the captured backward zeroes the flat buffer itself), and FusedAdamW consumes the flat
+            # buffer the all-reduce just averaged.
+            assert all(p.grad is not None and p.grad._base is model._engine._flat_grad for p in model.parameters())
 
             def fn(s):
                 graphs["fwd_bwd"].replay()
-                reduce_and_update()
+                reduce_and_update(zero=False)
         else:
             if world > 1:
                 model._engine.attach_reducer()
@@ -236,6 +253,14 @@ def main():
                     opt.step(grad_scale=1.0 / loss_scale), opt.zero_grad()
                 else:
                     reduce_and_update()
+    elif args.mode == "sheet":
+        from pssr2_amd.predict import predict_sheet
+        model.eval()
+        rng = np.random.default_rng(7 + rank)
+        sheet = torch.from_numpy(rng.integers(0, 256, size=(args.channels, 4096, 4096), dtype=np.uint8)).to(dev)
+        sheet_tiles = ((4096 - args.lr_res) // (args.lr_res - 32) + 1) ** 2
+        fn = lambda s: predict_sheet(model, sheet, tile_res=args.lr_res, overlap=32, margin=8, batch_size=max(args.batch, 128), device=dev, to_numpy=False)
+        use_graph = False
     else:
         model.eval()
         if use_graph:
@@ -270,7 +295,7 @@ def main():
     if rank == 0 and use_graph and args.dtype == "bf16":
         # the timed region replayed a hipGraph; time the same kernels once more in an instrumented eager pass
         timer.install()
-        eager = (lambda: (fwd_bwd(), opt.zero_grad())) if args.mode == "train" else infer_body
+        eager = (lambda: (fwd_bwd(), opt.zero_grad())) if args.mode == "train" else (infer_body if args.mode == "infer" else (lambda: fn(0)))
         for _ in range(2):
             eager()
         torch.cuda.synchronize()
@@ -278,8 +303,11 @@ def main():
         measured_in = "instrumented eager pass after the timed region (the timed region replays the same kernels from a hipGraph)"
     if rank == 0:
         conv = timer.summary()
-        tiles_per_s = world * args.batch * args.steps / elapsed
+        per_step = sheet_tiles if args.mode == "sheet" else args.batch
+        tiles_per_s = world * per_step * args.steps / elapsed
         gflop_tile = TRAIN_GFLOP_PER_TILE if args.mode == "train" else FWD_GFLOP_PER_TILE
+        if args.mode == "sheet":
+            args.batch = max(args.batch, 128)
         if args.model == "rdresunet":      # 53.575 GMAC fwd per tile
             gflop_tile = 321.45 if args.mode == "train" else 107.15
         scale = (args.lr_res / 128) ** 2

@@ -369,6 +369,19 @@ int pssr_head_conv_dgrad(const float* g_nchw, float g_scale, const float* w_oihw
 int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, int act_cs, int act_co, int blk,
                          float* dw_oihw, int n, int h, int w, int cin, int cout, int dtype, pssr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Whole-sheet prediction on the device (BASELINE config 5).
+ * pssr_sliding_tiles_u8: tiles [ntile][c][size][size] f32 = the row-major sliding windows tile0 .. tile0+ntile-1 of a uint8 sheet
+ *   [c][h][w] (pssr/data.py:629-638 `_sliding_window` + `_tensor_ready`; stride = size - overlap; remainders dropped).
+ * pssr_patch_tiles_u8: sheet [c][n_rows*step+overlap][n_cols*step+overlap] u8 = overlap-averaged stitching of u8 tiles
+ *   [n_rows*n_cols][c][size][size] with `margin` pixels trimmed on inner edges, then the uint8 cast (truncation):
+ *   pssr/util.py:116-137 `_patch_images` + pssr/util.py:101.  step = size - overlap (all in output pixels).
+ */
+int pssr_sliding_tiles_u8(const uint8_t* sheet, float* tiles, int c, int h, int w, int size, int stride, int tile0, int ntile,
+                          pssr_stream_t stream);
+int pssr_patch_tiles_u8(const uint8_t* tiles, uint8_t* sheet, int c, int n_rows, int n_cols, int size, int overlap, int margin,
+                        pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -358,14 +358,14 @@ template <int BN, int TAPS> struct Cfg2 {
     static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = HPI;
     static constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
     static constexpr int MI = MPIX / 32 / WM, NJ = BN / (32 * WN);
-    static constexpr int NSL = TAPS == 9 ? 3 : 2;                                  // weight slices per stage
+    static constexpr int NSL = TAPS == 9 ? 9 : 2;                                  // weight slices per stage (3x3: a whole chunk)
     static constexpr int A_PIX = TAPS == 9 ? HP : MPIX;                             // pixels of one staged image
     static constexpr int A_IMGS = TAPS == 9 ? 1 : NSL;                              // images per stage buffer
     static constexpr int A_BYTES = A_IMGS * A_PIX * 32, B_BYTES = NSL * BN * 32;
     static constexpr int A_ITEMS = (2 * A_IMGS * A_PIX + 255) / 256;
     static constexpr int B_PIECES = B_BYTES / 1024;                                 // 1-KiB LDS-DMA wave-instructions per stage
     static constexpr int E_BYTES = WM * 32 * BN * 4, RED_BYTES = 4 * BN * 2 * 4;
-    static constexpr int RING = TAPS == 9 ? 3 : 2;                                  // weight stages resident in LDS
+    static constexpr int RING = 2;                                                  // weight stages resident in LDS
     static constexpr int MAIN_BYTES = 2 * A_BYTES + RING * B_BYTES;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
 };
@@ -374,7 +374,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <typename T, int BN, int TAPS0>
-__global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, 1) void conv_igemm2_kernel(const ConvArgs p) {
     using C = Cfg2<BN, TAPS0>;
     using X = TT<T>;
     constexpr int EPS = X::EPS, KCH = X::KCH;
@@ -440,8 +440,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(con
     const int n0c = p.nchunks[0], n1c = p.nchunks[1];
     // stage -> (source, first chunk, first tap, slices).  3x3: 3 stages per source-0 chunk, then one 1-slice stage per
     // source-1 chunk (centre tap of the same halo geometry).  1x1: NSL chunks per stage, single source.
-    const int nst0 = (TAPS0 == 9) ? 3 * n0c : (n0c + C::NSL - 1) / C::NSL;
-    const int nst = nst0 + ((TAPS0 == 9) ? n1c : 0);
+    const int nst = (TAPS0 == 9) ? n0c + n1c : (n0c + C::NSL - 1) / C::NSL;
     u32x4 a_reg[C::A_ITEMS];
 
 #define V2_ISSUE_A(SRC, CHUNK)                                                                                    \
@@ -492,9 +491,9 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(con
 #define V2_ISSUE_B(S)                                                                                             \
     {                                                                                                             \
         const int s_ = (S);                                                                                       \
-        const bool src1_ = (TAPS0 == 9) && s_ >= nst0;                                                            \
-        const int chunk_ = (TAPS0 == 9) ? (src1_ ? s_ - nst0 : s_ / 3) : s_ * C::NSL;                             \
-        const int tap0_ = (TAPS0 == 9 && !src1_) ? (s_ % 3) * 3 : 0;                                              \
+        const bool src1_ = (TAPS0 == 9) && s_ >= n0c;                                                             \
+        const int chunk_ = (TAPS0 == 9) ? (src1_ ? s_ - n0c : s_) : s_ * C::NSL;                                  \
+        const int tap0_ = 0;                                                                                      \
         const int taps_ = (TAPS0 == 9 && !src1_) ? 9 : 1;                                                         \
         const char* wsrc_ = (const char*)p.w[src1_ ? 1 : 0];                                                      \
         char* bdst_ = Bbuf + (s_ % C::RING) * C::B_BYTES;                                                         \
@@ -513,23 +512,40 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(con
             }                                                                                                     \
         }                                                                                                         \
     }
-    // one stage = NSLICES weight slices against the staged image; everything compile-time except the buffers, so that the
-    // scheduler can run the LDS reads of slice i+1 under the MFMAs of slice i
-#define V2_COMPUTE(BSTAGE, AIMG, KY, NSLICES, KX0)                                                                \
+    // one stage = NSLICES weight slices against the staged image.  The fragments of slice i+1 are requested before the MFMAs
+    // of slice i are issued (two register sets, compile-time indices after unrolling), so a wave that is alone on its SIMD
+    // keeps the LDS latency under its own matrix work.
+#define V2_FRAGS(SET, SL, AIMG, KY3, KX0)                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                    \
+            int pa;                                                                                               \
+            if (TAPS0 == 9) pa = a_p0[mi] + ((KY3) ? ((SL) / 3) : 1) * C::HW2 + ((KY3) ? ((SL) % 3) : (KX0));     \
+            else pa = (SL) * C::A_PIX + a_p0[mi];                                                                 \
+            const int pin = (TAPS0 == 9) ? pa : a_p0[mi];                                                         \
+            af[SET][mi] = *(const u32x4*)((AIMG) + pa * 32 + ((h ^ ((pin >> 3) & 1)) << 4));                      \
+        }                                                                                                         \
+        _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[SET][nj] = *(const u32x4*)(bs_ + (SL) * BN * 32 + b_off[nj]); \
+    }
+#define V2_COMPUTE(BSTAGE, AIMG, KY3, NSLICES, KX0)                                                               \
     {                                                                                                             \
         const char* bs_ = Bbuf + (BSTAGE) * C::B_BYTES;                                                           \
+        u32x4 af[2][C::MI], bf[2][C::NJ];                                                                         \
+        V2_FRAGS(0, 0, AIMG, KY3, KX0)                                                                            \
         _Pragma("unroll") for (int sl = 0; sl < (NSLICES); ++sl) {                                                \
-            u32x4 af[C::MI], bf[C::NJ];                                                                           \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                \
-                int pa;                                                                                           \
-                if (TAPS0 == 9) pa = a_p0[mi] + (KY) * C::HW2 + (KX0) + sl;                                       \
-                else pa = sl * C::A_PIX + a_p0[mi];                                                               \
-                const int pin = (TAPS0 == 9) ? pa : a_p0[mi];                                                     \
-                af[mi] = *(const u32x4*)((AIMG) + pa * 32 + ((h ^ ((pin >> 3) & 1)) << 4));                       \
-            }                                                                                                     \
-            _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(bs_ + sl * BN * 32 + b_off[nj]); \
+            if (sl + 1 < (NSLICES)) V2_FRAGS((sl + 1) & 1, sl + 1, AIMG, KY3, KX0)                                \
             _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
+                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[sl & 1][mi], bf[sl & 1][nj]); \
+            /* pin the interleave: one fragment read of the NEXT slice behind each MFMA of this one (left alone, the  \
+               scheduler minimises registers and serialises read -> wait -> 2 MFMAs) */                             \
+            if (sl + 1 < (NSLICES)) {                                                                             \
+                _Pragma("unroll") for (int q = 0; q < C::MI + C::NJ; ++q) {                                       \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+                }                                                                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ - (C::MI + C::NJ), 0);                  \
+            } else {                                                                                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ, 0);                                    \
+            }                                                                                                     \
         }                                                                                                         \
     }
 
@@ -543,53 +559,31 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(con
       else if (n_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                          \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     if constexpr (TAPS0 == 9) {
-        static_assert((C::B_PIECES + 3) / 4 <= 3, "V2_WAIT_BUT covers at most 3 DMA instructions per wave and stage");
-        // image index i: source-0 chunks 0..n0c-1, then source-1 chunks.  Weight stages run two ahead in a 3-deep ring;
-        // the barriers are raw s_barrier (a __syncthreads() would drain the DMAs in flight).
+        // stage = one 32-byte channel chunk of source 0 (9 taps) or one chunk of the 1x1 source 1 (centre tap of its halo
+        // image); weights and image of stage s+1 are requested at the start of stage s (LDS-DMA / registers) and must have
+        // landed at its end: one wait + one barrier per stage
         const int nimg = n0c + n1c;
         if (n0c > 0) { V2_ISSUE_A(0, 0) } else { V2_ISSUE_A(1, 0) }
         V2_ISSUE_B(0)
-        if (nst > 1) V2_ISSUE_B(1)
         if (n0c > 0) { V2_COMMIT_A(0, 0, Abuf) } else { V2_COMMIT_A(1, 0, Abuf) }
-        V2_WAIT_BUT(nst > 1 ? nb_issued : 0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int ring = 0;               // ring slot of the stage being multiplied
-#define V2_STAGE_TAIL(S, LAST, MORE, NSRC, NCHUNK)                                                                \
-        if ((LAST) && (MORE)) {                                                                                   \
-            if (NSRC) V2_COMMIT_A(1, NCHUNK, Abuf + (abuf ^ 1) * C::A_BYTES) else V2_COMMIT_A(0, NCHUNK, Abuf + (abuf ^ 1) * C::A_BYTES) \
-        }                                                                                                         \
-        V2_WAIT_BUT(nb_issued)      /* stage S+1's weights have landed; stage S+2's may still fly */              \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-        __builtin_amdgcn_s_barrier();                                                                             \
-        ring = ring == C::RING - 1 ? 0 : ring + 1;
-        for (int c = 0; c < n0c; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < nimg; ++c) {
             const bool more = c + 1 < nimg;
             const int nsrc = (c + 1 >= n0c) ? 1 : 0, nchunk = nsrc ? c + 1 - n0c : c + 1;
-            const int s = 3 * c;
-            // row 0: request the next image first (its register loads must be OLDER than this stage's DMAs)
-            if (more) { if (nsrc) V2_ISSUE_A(1, nchunk) else V2_ISSUE_A(0, nchunk) }
-            if (s + 2 < nst) V2_ISSUE_B(s + 2) else nb_issued = 0;
-            V2_COMPUTE(ring, Abuf + abuf * C::A_BYTES, 0, 3, 0)
-            V2_STAGE_TAIL(s, false, more, nsrc, nchunk)
-            if (s + 3 < nst) V2_ISSUE_B(s + 3) else nb_issued = 0;
-            V2_COMPUTE(ring, Abuf + abuf * C::A_BYTES, 1, 3, 0)
-            V2_STAGE_TAIL(s + 1, false, more, nsrc, nchunk)
-            if (s + 4 < nst) V2_ISSUE_B(s + 4) else nb_issued = 0;
-            V2_COMPUTE(ring, Abuf + abuf * C::A_BYTES, 2, 3, 0)
-            V2_STAGE_TAIL(s + 2, true, more, nsrc, nchunk)
+            if (more) {
+                if (nsrc) V2_ISSUE_A(1, nchunk) else V2_ISSUE_A(0, nchunk)
+                V2_ISSUE_B(c + 1)
+            }
+            if (c < n0c) V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 1, 9, 0)
+            else V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 0, 1, 1)
+            if (more) {
+                if (nsrc) V2_COMMIT_A(1, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES) else V2_COMMIT_A(0, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             abuf ^= 1;
         }
-        for (int c1 = 0; c1 < n1c; ++c1) {      // 1x1 second source: centre tap of its halo image
-            const int s = nst0 + c1;
-            const bool more = c1 + 1 < n1c;
-            if (more) V2_ISSUE_A(1, c1 + 1)
-            if (s + 2 < nst) V2_ISSUE_B(s + 2) else nb_issued = 0;
-            V2_COMPUTE(ring, Abuf + abuf * C::A_BYTES, 1, 1, 1)
-            V2_STAGE_TAIL(s, true, more, 1, c1 + 1)
-            abuf ^= 1;
-        }
-#undef V2_STAGE_TAIL
     } else {
         V2_ISSUE_B(0)
         V2_ISSUE_A(0, 0)
@@ -607,6 +601,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void conv_igemm2_kernel(con
         }
     }
 #undef V2_WAIT_BUT
+#undef V2_FRAGS
 #undef V2_ISSUE_A
 #undef V2_COMMIT_A
 #undef V2_ISSUE_B

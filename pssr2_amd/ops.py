@@ -401,3 +401,23 @@ def head_conv_dgrad(g, g_scale, weight, act, dact, blk, n, h, w, cin, cout, dtyp
 def head_conv_wgrad(g, g_scale, act, blk, dw, n, h, w, cin, cout, dtype):
     L.check(L.lib().pssr_head_conv_wgrad(L.ptr(g), C.c_float(g_scale), L.ptr(act), act.shape[-1], 0, blk, L.ptr(dw), n, h, w, cin, cout, dtype,
                                          L.stream_ptr()), "pssr_head_conv_wgrad")
+
+
+# ----------------------------------------------------------------------------------------------
+# whole-sheet prediction (csrc/tiles.hip)
+def sliding_tiles_u8(sheet, size, stride, tile0, ntile):
+    """uint8 sheet [C,H,W] on the device -> float32 tiles [ntile, C, size, size] (row-major sliding windows)."""
+    c, h, w = sheet.shape
+    out = torch.empty(ntile, c, size, size, dtype=torch.float32, device=sheet.device)
+    L.check(L.lib().pssr_sliding_tiles_u8(L.ptr(sheet), L.ptr(out), c, h, w, size, stride, tile0, ntile, L.stream_ptr()), "pssr_sliding_tiles_u8")
+    return out
+
+
+def patch_tiles_u8(tiles, n_rows, n_cols, overlap, margin):
+    """uint8 tiles [n_rows*n_cols, C, S, S] -> uint8 sheet [C, n_rows*step+overlap, n_cols*step+overlap] (overlap-averaged)."""
+    t, c, size, _ = tiles.shape
+    assert t == n_rows * n_cols and tiles.dtype == torch.uint8 and tiles.is_contiguous()
+    step = size - overlap
+    out = torch.empty(c, n_rows * step + overlap, n_cols * step + overlap, dtype=torch.uint8, device=tiles.device)
+    L.check(L.lib().pssr_patch_tiles_u8(L.ptr(tiles), L.ptr(out), c, n_rows, n_cols, size, overlap, margin, L.stream_ptr()), "pssr_patch_tiles_u8")
+    return out

@@ -77,3 +77,42 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
             cur_idx += batch_size
     if out_dir is None:
         return outs
+
+
+def predict_sheet(model: nn.Module, sheet, tile_res: int = 128, overlap: int = 32, margin: int = 0, batch_size: int = 128,
+                  device: str = "cuda", to_numpy: bool = True):
+    r"""Whole-sheet prediction entirely on the device: what ``predict_images`` on a ``SlidingDataset`` in LR mode
+    (pssr/data.py:132-266, pssr/predict.py:11-83) followed by ``reassemble_sheets`` (pssr/util.py:54-137) computes, without
+    the per-tile host round trips.  ``sheet``: uint8 array or tensor [C, H, W] (or [H, W]) of the low-resolution image.
+    Tiles of ``tile_res`` LR pixels with ``overlap`` are cut on the device, predicted in batches, truncated to uint8
+    (``_pred_array``), and stitched with overlap averaging and ``margin`` trimming (in LR pixels times the model's scale,
+    as upstream).  Returns uint8 [C_out, H', W'] with H' = (n_rows*(tile_res-overlap)+overlap)*scale."""
+    if margin > overlap:
+        raise ValueError(f"The value of margin cannot be greater than overlap. Given {margin} and {overlap} respectively.")
+    sheet = torch.as_tensor(np.asarray(sheet) if not torch.is_tensor(sheet) else sheet)
+    if sheet.dim() == 2:
+        sheet = sheet[None]
+    if sheet.dtype != torch.uint8:
+        raise ValueError("predict_sheet expects a uint8 sheet (the reference's uint8 tif path)")
+    sheet = sheet.to(device).contiguous()
+    c, h, w = sheet.shape
+    if h < tile_res or w < tile_res:
+        raise ValueError(f"sheet {h}x{w} is smaller than one tile ({tile_res})")
+    stride = tile_res - overlap
+    n_rows, n_cols = (h - tile_res) // stride + 1, (w - tile_res) // stride + 1
+    n_tiles = n_rows * n_cols
+    model.to(device)
+    model.eval()
+    preds = None
+    with torch.no_grad():
+        for t0 in range(0, n_tiles, batch_size):
+            nt = min(batch_size, n_tiles - t0)
+            lr = ops.sliding_tiles_u8(sheet, tile_res, stride, t0, nt)
+            y = model(lr).contiguous().float()
+            if preds is None:
+                preds = torch.empty(n_tiles, *y.shape[1:], dtype=torch.uint8, device=y.device)
+            ops.clip_u8(y, preds[t0:t0 + nt])
+    scale = preds.shape[-1] // tile_res
+    # upstream passes overlap*lr_scale and the raw margin to _patch_images (pssr/util.py:99)
+    out = ops.patch_tiles_u8(preds, n_rows, n_cols, overlap * scale, margin)
+    return out.cpu().numpy() if to_numpy else out

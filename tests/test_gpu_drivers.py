@@ -81,3 +81,45 @@ def test_predict_images_dict_and_pred_array(golden, tmp_path):
     assert len(list((tmp_path / "p").glob("x_sheet0_*_0.tif"))) == 9
     with pytest.raises(ValueError):
         predict_images(model, ds, device="cuda", norm=True, out_dir=None)
+
+
+def test_device_tiling_and_patching_bit_exact(golden):
+    """csrc/tiles.hip vs the reference's fixtures: `_patch_images` (+ the uint8 cast of reassemble_sheets) and `_sliding_window`."""
+    from pssr2_amd import ops
+    g = golden("post.npz")
+    tiles = torch.tensor(g["patch_tiles"]).cuda()                  # (12, 32, 32) uint8
+    for name in "abc":
+        n_cols, n_rows, ov, mg = (int(v) for v in g[f"patch_{name}_args"])
+        want = np.asarray(g[f"patch_{name}"], dtype=np.uint8)      # the cast at pssr/util.py:101
+        got = ops.patch_tiles_u8(tiles[:, None].contiguous(), n_rows, n_cols, ov, mg)[0].cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    sheet = torch.tensor(g["sheet"]).cuda()                        # (1, 100, 90) uint8; tile 5 of size 32, stride 24
+    t = ops.sliding_tiles_u8(sheet, 32, 24, 5, 1)[0].cpu().numpy()
+    np.testing.assert_array_equal(t, g["tile5"].astype(np.float32))
+    with pytest.raises(RuntimeError, match="margin"):
+        ops.patch_tiles_u8(tiles[:, None].contiguous(), 3, 4, 4, 5)
+
+
+def test_predict_sheet_matches_tile_pipeline():
+    """Whole-sheet prediction on the device == predict_images on the sliding dataset + host reassembly (reference semantics)."""
+    from oracle import model_ref as M
+    from pssr2_amd.data import SlidingArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images, predict_sheet
+    from pssr2_amd.util import _patch_images
+    model = ResUNet(hidden=[16, 32])
+    model.load_state_dict(M.make_state_dict(hidden=(16, 32), seed=6))
+    model.compute_dtype = torch.bfloat16
+    rng = np.random.default_rng(3)
+    sheet = rng.integers(0, 256, size=(1, 104, 88), dtype=np.uint8)
+    tile, ov, mg = 32, 8, 3
+    ds = SlidingArrayDataset([sheet], hr_res=tile, overlap=ov)
+    preds = predict_images(model, ds, device="cuda", batch_size=5, out_dir=None)
+    n_rows, n_cols = (104 - tile) // (tile - ov) + 1, (88 - tile) // (tile - ov) + 1
+    batched = np.asarray([preds[f"sheet0_{t}_0"].squeeze() for t in range(n_rows * n_cols)])
+    want = np.asarray(_patch_images(batched, n_cols, n_rows, ov * 4, mg), dtype=np.uint8)
+    got = predict_sheet(model, sheet, tile_res=tile, overlap=ov, margin=mg, batch_size=7)
+    assert got.shape == (1, (n_rows * (tile - ov) + ov) * 4, (n_cols * (tile - ov) + ov) * 4)
+    np.testing.assert_array_equal(got[0], want)
+    with pytest.raises(ValueError, match="margin"):
+        predict_sheet(model, sheet, tile_res=tile, overlap=4, margin=5)
