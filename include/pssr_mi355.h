@@ -127,9 +127,15 @@ typedef struct pssr_conv_desc {
      * NHWC tensor whose channels were ordered sub-pixel-major needs no data movement at all.    */
     int32_t in0_blk, out_blk, aux_blk;
     float out_scale, out_shift; /* EPI_FINAL only                                              */
+    /* optional scratch for split-K (layers whose tiles do not fill the chip): pssr_conv2d_workspace_bytes(desc) bytes,
+     * uninitialised, caller-owned; NULL (or too small) simply disables the split                                   */
+    void* workspace; int64_t workspace_bytes;
 } pssr_conv_desc;
 
 int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
+/* bytes of `workspace` with which pssr_conv2d would split K for this shape (0: no split); negative = PSSR_ERR_*.  Pointers
+ * in `desc` are ignored. */
+int64_t pssr_conv2d_workspace_bytes(const pssr_conv_desc* desc);
 /* Tuning / test knob: which main loop pssr_conv2d uses for images >= 16x16.  0 (default): always the 128-pixel tiles; 1:
  * the pipelined 256-pixel LDS-DMA loop when the grid fills the chip; 2: the pipelined loop whenever the shape allows.
  * Returns the previous mode (any other argument only queries).  Also settable with the environment variable PSSR_IGEMM_V2. */

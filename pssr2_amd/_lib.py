@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("stats", c_void_p),
         ("in0_blk", C.c_int32), ("out_blk", C.c_int32), ("aux_blk", C.c_int32),
         ("out_scale", C.c_float), ("out_shift", C.c_float),
+        ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -70,6 +71,7 @@ def lib():
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.pssr_last_error.restype = C.c_char_p
         _lib.pssr_packed_weight_bytes.restype = C.c_int64
+        _lib.pssr_conv2d_workspace_bytes.restype = C.c_int64
     return _lib
 
 

@@ -33,6 +33,7 @@ struct ConvArgs {
     double* stats;
     int in0_blk, out_blk, aux_blk;
     float out_scale, out_shift;
+    int ksplit; float* ws;      // split-K: blockIdx.y owns a chunk range, raw accumulators go to ws (single-source convs only)
 };
 
 template <int GEO> struct Geo;
@@ -318,17 +319,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 
     // source 0 (TAPS0 taps) then the optional 1x1 source 1; the loads of the next chunk fly during the MFMAs
-    const int n0c = p.nchunks[0];
-    PSSR_ISSUE(0, TAPS0)
-    for (int i = 0; i < n0c; ++i) {
+    // split-K (p.ksplit > 1, single source): blockIdx.y multiplies chunks [cb, n0c) of its slice only
+    int cb = 0, n0c = p.nchunks[0];
+    if (p.ksplit > 1) {
+        const int per = (n0c + p.ksplit - 1) / p.ksplit;
+        cb = blockIdx.y * per;
+        n0c = cb + per < n0c ? cb + per : n0c;
+    }
+    if (cb < n0c) PSSR_ISSUE(cb, TAPS0)
+    for (int i = cb; i < n0c; ++i) {
         PSSR_COMMIT(i, TAPS0)
         __syncthreads();
         if (i + 1 < n0c) PSSR_ISSUE(i + 1, TAPS0)
-        else if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
+        else if (i + 1 < total && p.ksplit <= 1) PSSR_ISSUE(i + 1, 1)
         PSSR_COMPUTE(TAPS0)
         __syncthreads();
     }
-    for (int i = n0c; i < total; ++i) {
+    for (int i = n0c; i < total && p.ksplit <= 1; ++i) {
         PSSR_COMMIT(i, 1)
         __syncthreads();
         if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
@@ -339,6 +346,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #undef PSSR_COMMIT
 #undef PSSR_COMPUTE
 
+    if (p.ksplit > 1) {
+        // raw accumulators of this K slice: ws[((block * ksplit + slice) * 16*MI*NJ + j) * 256 + tid] as float4 (coalesced)
+        float4* dst = (float4*)p.ws + ((long)blockIdx.x * p.ksplit + blockIdx.y) * (4 * C::MI * C::NJ) * 256 + tid;
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[((mi * C::NJ + nj) * 4 + q) * 256] = make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
+        return;
+    }
+    conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
+}
+
+// second pass of a split-K convolution: sum the K slices of a tile and run the ordinary epilogue
+template <typename T, int BN, int GEO>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
+    using C = Cfg<BN, GEO>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    const int tn = bid % p.tiles_n;
+    int tmi = bid / p.tiles_n;
+    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
+    const int tile_y = tmi % p.tiles_y;
+    const int tile_i = tmi / p.tiles_y;
+    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
+    f32x16 acc[C::MI][C::NJ];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+    for (int kz = 0; kz < p.ksplit; ++kz) {
+        const float4* src = (const float4*)p.ws + ((long)bid * p.ksplit + kz) * (4 * C::MI * C::NJ) * 256 + tid;
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = src[((mi * C::NJ + nj) * 4 + q) * 256];
+                    acc[mi][nj][4 * q] += v.x; acc[mi][nj][4 * q + 1] += v.y; acc[mi][nj][4 * q + 2] += v.z; acc[mi][nj][4 * q + 3] += v.w;
+                }
+    }
     conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
 }
 
@@ -639,7 +693,7 @@ int g_v2_mode = -1;
 template <typename T, int BN>
 bool use_v2(const ConvArgs& a) {
     if (g_v2_mode < 0) { const char* e = getenv("PSSR_IGEMM_V2"); g_v2_mode = e ? atoi(e) : 0; }
-    if (!g_v2_mode || a.W < 16 || a.H < 16) return false;
+    if (!g_v2_mode || a.W < 16 || a.H < 16 || a.ksplit < 0) return false;      // (ksplit < 0: workspace-size query)
     if (a.taps[0] == 1 && a.nchunks[1] != 0) return false;
     if (g_v2_mode == 2) return true;
     const long blocks = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.N * cdiv(a.cout, BN);
@@ -655,12 +709,26 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     p.tiles_n = cdiv(a.cout, BN);
     const long blocks = (long)p.tiles_x * p.tiles_y * cdiv(a.N, C::NI) * p.tiles_n;
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
+    // split-K when the tiles do not fill the chip and K is long: ~384 workgroups, >= 4 chunks per slice, <= 8 slices
+    int ksplit = 1;
+    if (BN >= 64 && a.nchunks[1] == 0 && a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
+        ksplit = (int)((384 + blocks - 1) / blocks);
+        if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
+        if (ksplit > 8) ksplit = 8;
+    }
+    const long ws_bytes = ksplit > 1 ? blocks * ksplit * (long)(64 * C::MI * C::NJ) * 256 : 0;
+    if (a.ksplit < 0) { *(long*)a.ws = ws_bytes; return PSSR_OK; }          // workspace-size query
+    if (ksplit > 1 && (a.ws == nullptr || (long)a.ksplit * 1024 < ws_bytes)) ksplit = 1;   // caller gave no (or too small a) workspace
+    p.ksplit = ksplit;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_splitk_finish_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES, stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL((conv_splitk_finish_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -701,13 +769,23 @@ extern "C" int pssr_conv2d_pipeline_mode(int mode) {
     return old;
 }
 
-extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
+static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* query_ws);
+
+extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) { return conv2d_entry(d, stream, nullptr); }
+
+extern "C" int64_t pssr_conv2d_workspace_bytes(const pssr_conv_desc* d) {
+    long bytes = 0;
+    const int rc = conv2d_entry(d, nullptr, &bytes);
+    return rc != PSSR_OK ? (int64_t)rc : (int64_t)bytes;
+}
+
+static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* query_ws) {
     PSSR_CHECK(d != nullptr, PSSR_ERR_ARG, "conv2d: null desc");
     PSSR_CHECK(d->dtype == PSSR_F32 || d->dtype == PSSR_BF16 || d->dtype == PSSR_F16, PSSR_ERR_ARG, "conv2d: bad dtype %d", d->dtype);
     const int kch = d->dtype == PSSR_F32 ? 8 : 16;
     const int esz = d->dtype == PSSR_F32 ? 4 : 2;
     PSSR_CHECK(d->n > 0 && d->h > 0 && d->w > 0, PSSR_ERR_ARG, "conv2d: bad shape %dx%dx%d", d->n, d->h, d->w);
-    PSSR_CHECK(d->in0 && d->w0 && d->out, PSSR_ERR_ARG, "conv2d: null pointer");
+    PSSR_CHECK(query_ws || (d->in0 && d->w0 && d->out), PSSR_ERR_ARG, "conv2d: null pointer");
     PSSR_CHECK(d->cin0 > 0 && d->cin0 % kch == 0, PSSR_ERR_ARG, "conv2d: cin0=%d must be a positive multiple of %d", d->cin0, kch);
     PSSR_CHECK(d->taps0 == 9 || d->taps0 == 1, PSSR_ERR_ARG, "conv2d: taps0=%d", d->taps0);
     PSSR_CHECK((d->in0_cstride * esz) % 16 == 0 && (d->in0_coff * esz) % 16 == 0, PSSR_ERR_ARG, "conv2d: in0 stride/offset not 16-byte aligned");
@@ -754,6 +832,11 @@ extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) {
     a.in0_blk = d->in0_blk; a.out_blk = d->out_blk; a.aux_blk = d->aux_blk;
     a.out_scale = d->out_scale; a.out_shift = d->out_shift;
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
+    long ws_query = 0;
+    if (query_ws) { a.ksplit = -1; a.ws = (float*)&ws_query; }
+    else { a.ws = (float*)d->workspace; a.ksplit = d->workspace ? (int)(d->workspace_bytes / 1024) : 0; }
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : d->dtype == PSSR_F16 ? launch_bn<f16_t>(a, s) : launch_bn<float>(a, s);
+    const int rc = d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : d->dtype == PSSR_F16 ? launch_bn<f16_t>(a, s) : launch_bn<float>(a, s);
+    if (query_ws) *query_ws = ws_query;
+    return rc;
 }

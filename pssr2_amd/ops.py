@@ -80,6 +80,10 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
     d.in0_blk, d.out_blk, d.aux_blk, d.out_scale, d.out_shift = in0_blk, out_blk, aux_blk, out_scale, out_shift
     if epilogue == L.EPI_FINAL:      # f32 NCHW output [n, cout, h, w]
         d.out_cstride, d.out_coff = cout, 0
+    ws_bytes = L.lib().pssr_conv2d_workspace_bytes(C.byref(d))      # > 0: the library wants to split K (under-filled grid)
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device)
+        d.workspace, d.workspace_bytes = L.ptr(ws), ws_bytes
     L.check(L.lib().pssr_conv2d(C.byref(d), L.stream_ptr()), "pssr_conv2d")
     return out
 

@@ -45,6 +45,9 @@ CASES += [
     (3, 16, 64, 16, 40, 3),      # BN = 64, partial tiles in x, one chunk
     (2, 80, 192, 24, 24, 1),     # 1x1, odd chunk count (5), two N tiles, partial tiles
     (1, 32, 72, 36, 20, 1),      # 1x1, BN = 128 with cout not a multiple of 32
+    (2, 256, 128, 16, 16, 3),    # few tiles, long K: split-K (4 slices) + finish kernel
+    (3, 640, 64, 8, 8, 1),       # 1x1 split-K, BN = 64, GEO 1
+    (1, 144, 200, 12, 12, 3),    # split-K with an uneven chunk split and partial tiles
 ]
 
 
