@@ -1,767 +1,12 @@
-// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 (MI355X): forward and input-gradient.
-//
-//   M = output pixels (128 per workgroup: a TH x TW patch of NI images), N = output channels
-//   (BN per workgroup), K = taps x input channels, walked in 32-byte channel chunks.
-//
-// Per K-chunk the workgroup stages ONE halo tile of the input ((TH+2)x(TW+2) pixels x 32 B) and
-// the 9 tap slices of the packed weights into LDS; the 9 taps are then 9 shifted reads of the same
-// LDS halo (so HBM/L2 -> LDS input traffic is 1.4x the tile instead of 9x), each feeding 32x32
-// MFMA tiles (v_mfma_f32_32x32x16_bf16, or 4 x v_mfma_f32_32x32x2_f32 in the exact-f32 build).
-// Staging is register-mediated: BatchNorm+ReLU of the producing layer and the zero padding are
-// applied between the global load and the LDS write, and the loads of chunk i+1 are in flight
-// while chunk i is multiplied.  The accumulators leave through LDS so that every epilogue
-// (bias, ReLU, residual tail, ReLU mask, f64 BatchNorm statistics) runs on pixel-major rows and
-// the stores are coalesced along channels.
-#include <type_traits>
-
+// C ABI of the implicit-GEMM convolution (forward and input-gradient): argument checks and dispatch on the storage type.
+// The kernels live in conv_igemm_impl.h, compiled once per type by conv_igemm_{bf16,f16,f32}.hip.
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_igemm_args.h"
 
-namespace {
-
-struct ConvArgs {
-    int N, H, W;
-    int tiles_x, tiles_y, tiles_n;
-    const void* in[2]; int in_cs[2]; int in_co[2]; int nchunks[2]; int taps[2]; const void* w[2];
-    int prologue; const float* pro_scale; const float* pro_shift;
-    void* out; int out_cs, out_co, cout, n_pad;
-    const float* bias;
-    int epi, flags;
-    const void* aux; int aux_cs, aux_co;
-    const float* aux_scale; const float* aux_shift; const float* aux_mean; const float* aux_invstd;
-    double* stats;
-    int in0_blk, out_blk, aux_blk;
-    float out_scale, out_shift;
-    int ksplit; float* ws;      // split-K: blockIdx.y owns a chunk range, raw accumulators go to ws (single-source convs only)
-};
-
-template <int GEO> struct Geo;
-template <> struct Geo<0> { static constexpr int TWL = 4, THL = 3; };   // 8 x 16, 1 image
-template <> struct Geo<1> { static constexpr int TWL = 3, THL = 3; };   // 8 x 8,  2 images
-template <> struct Geo<2> { static constexpr int TWL = 2, THL = 2; };   // 4 x 4,  8 images
-template <> struct Geo<3> { static constexpr int TWL = 1, THL = 1; };   // 2 x 2, 32 images
-template <> struct Geo<4> { static constexpr int TWL = 0, THL = 0; };   // 1 x 1, 128 images
-
-template <int BN, int GEO> struct Cfg {
-    static constexpr int TWL = Geo<GEO>::TWL, THL = Geo<GEO>::THL;
-    static constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
-    static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI;
-    static constexpr int A_ITEMS = (2 * HP + 255) / 256;
-    static constexpr int A_BYTES = HP * 32;
-    static constexpr int B_BYTES = 9 * BN * 32;
-    static constexpr int B_ITEMS = (9 * BN * 2 + 255) / 256;
-    static constexpr int WM = (BN == 32) ? 4 : 2, WN = 4 / WM;
-    static constexpr int MI = 4 / WM, NJ = BN / (32 * WN);
-    static constexpr int E_BYTES = WM * 32 * BN * 4;
-    static constexpr int RED_BYTES = 4 * BN * 2 * 4;
-    static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
-    static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-};
-
-// Epilogue shared by both main loops: the accumulators leave through LDS so that bias / ReLU / residual tail / ReLU mask /
-// GELU derivative / f64 BatchNorm statistics run on pixel-major rows and the stores are coalesced along channels.
-// CFG provides WM, WN, MI, NJ, TW, TH, TWL, THL, E_BYTES; BN the channel tile.
-template <typename T, int BN, class C>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
-    using X = TT<T>;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int h = lane >> 5, r = lane & 31;
-    float* Es = (float*)smem;                       // [WM*32][BN] f32
-    float* Red = (float*)(smem + C::E_BYTES);       // [4 waves][BN][2]
-    constexpr int CG = BN / 4;                      // 4-channel groups per row
-    constexpr int PASSES = C::WM * 32 * CG / 256;
-    const int c4 = tid % CG;
-    const int n_base = n0 + c4 * 4;
-    const bool n_ok = n_base < p.cout;
-    float bias[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0}, xh[4] = {0, 0, 0, 0}, xm[4] = {0, 0, 0, 0}, xi[4] = {0, 0, 0, 0};
-    if (n_ok) {
-        if (p.bias) {
-            if (p.epi == PSSR_EPI_FINAL) { for (int e = 0; e < 4; ++e) if (n_base + e < p.cout) bias[e] = p.bias[n_base + e]; }
-            else load4(p.bias + n_base, bias);
-        }
-        if (p.epi == PSSR_EPI_TAIL || p.epi == PSSR_EPI_DGRAD_MASK) { load4(p.aux_scale + n_base, xs); load4(p.aux_shift + n_base, xh); }
-        if (p.epi == PSSR_EPI_DGRAD_MASK && (p.flags & PSSR_FLAG_STATS)) {
-            load4(p.aux_mean + n_base, xm); load4(p.aux_invstd + n_base, xi);
-        }
-    }
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    T* outp = (T*)p.out;
-    const T* auxp = (const T*)p.aux;
-
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-        if (mi) __syncthreads();
-#pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int col = wn * C::NJ * 32 + nj * 32 + r;
-                Es[row * BN + col] = acc[mi][nj][e];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int piece = tid + ps * 256;
-            const int row = piece / CG;
-            const int m = (row >> 5) * C::MI * 32 + mi * 32 + (row & 31);
-            const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
-            const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
-            if (!(n_ok && gi < p.N && gy < p.H && gx < p.W)) continue;
-            float v[4];
-            load4(Es + row * BN + c4 * 4, v);
-            if (p.epi == PSSR_EPI_FINAL) {
-                float* of = (float*)p.out;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n_base + e < p.cout)
-                        of[(((long)gi * p.cout + n_base + e) * p.H + gy) * p.W + gx] = fmaf(v[e] + bias[e], p.out_scale, p.out_shift);
-                continue;
-            }
-            const long pix = pix_index(gi, gy, gx, p.H, p.W, p.out_blk);
-            if (p.epi == PSSR_EPI_STORE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] += bias[e];
-                    if (p.flags & PSSR_FLAG_RELU) v[e] = fmaxf(v[e], 0.f);
-                }
-            } else {
-                float a[4];
-                load4(auxp + pix_index(gi, gy, gx, p.H, p.W, p.aux_blk) * p.aux_cs + p.aux_co + n_base, a);
-                if (p.epi == PSSR_EPI_TAIL) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
-                } else if (p.epi == PSSR_EPI_DGRAD_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (fmaf(a[e], xs[e], xh[e]) > 0.f) ? v[e] : 0.f;
-                        a[e] = (a[e] - xm[e]) * xi[e];       // xhat
-                    }
-                }
-                if (p.flags & PSSR_FLAG_STATS) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float g = X::round(v[e]); s1[e] += g; s2[e] += g * a[e]; }
-                }
-            }
-            if (p.epi == PSSR_EPI_STORE && (p.flags & PSSR_FLAG_STATS)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float g = X::round(v[e]); s1[e] += g; s2[e] += g * g; }
-            }
-            store4(outp + pix * p.out_cs + p.out_co + n_base, v);
-        }
-    }
-    if (p.flags & PSSR_FLAG_STATS) {
-#pragma unroll
-        for (int off = 32; off >= CG; off >>= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off); s2[e] += __shfl_xor(s2[e], off); }
-        if (lane < CG) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Red[(wave * BN + lane * 4 + e) * 2 + 0] = s1[e];
-                Red[(wave * BN + lane * 4 + e) * 2 + 1] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.cout) {
-            float t1 = 0, t2 = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { t1 += Red[(w * BN + tid) * 2]; t2 += Red[(w * BN + tid) * 2 + 1]; }
-            double* st = p.stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * p.cout;
-            atomicAdd(st + n0 + tid, (double)t1);
-            atomicAdd(st + p.cout + n0 + tid, (double)t2);
-        }
-    }
-}
-
-template <typename T, int BN, int GEO, int TAPS0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
-    using C = Cfg<BN, GEO>;
-    using X = TT<T>;
-    constexpr int EPS = X::EPS, KCH = X::KCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;
-    char* Bs = smem + C::A_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int h = lane >> 5, r = lane & 31;
-
-    const int bid = blockIdx.x;
-    const int tn = bid % p.tiles_n;
-    int tmi = bid / p.tiles_n;
-    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
-    const int tile_y = tmi % p.tiles_y;
-    const int tile_i = tmi / p.tiles_y;
-    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
-
-    // ---- per-thread staging descriptors for the input halo (same pixels for every chunk)
-    long a_pix[C::A_ITEMS], a_pix1[C::A_ITEMS];   // source 0 (possibly blocked order); source 1 is always plain NHWC
-    int a_lds[C::A_ITEMS];
-    bool a_ok[C::A_ITEMS];
-    int a_half[C::A_ITEMS];
-#pragma unroll
-    for (int it = 0; it < C::A_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        const int pp = idx >> 1, half = idx & 1;
-        const int img = pp / C::HPI, rem = pp % C::HPI;
-        const int hy = rem / C::HW2, hx = rem % C::HW2;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
-        const bool inb = (idx < 2 * C::HP) && gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_ok[it] = inb;
-        a_pix[it] = inb ? pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) : 0;
-        a_pix1[it] = inb ? ((long)gi * p.H + gy) * p.W + gx : 0;
-        a_lds[it] = (idx < 2 * C::HP) ? (pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
-        a_half[it] = half;
-    }
-    // ---- fragment read bases
-    int a_p0[C::MI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-        const int m = wm * C::MI * 32 + mi * 32 + r;
-        const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
-        a_p0[mi] = img * C::HPI + ty * C::HW2 + tx;
-    }
-    int b_off[C::NJ];
-#pragma unroll
-    for (int nj = 0; nj < C::NJ; ++nj) {
-        const int n = wn * C::NJ * 32 + nj * 32 + r;
-        b_off[nj] = n * 32 + ((h ^ ((n >> 3) & 1)) << 4);
-    }
-
-    f32x16 acc[C::MI][C::NJ];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
-
-    const int total = p.nchunks[0] + p.nchunks[1];
-    u32x4 a_reg[C::A_ITEMS];
-    u32x4 b_reg[C::B_ITEMS];
-
-    // NB: the three phases are macros, not lambdas: with lambdas hipcc keeps a_reg/b_reg in scratch.
-#define PSSR_ISSUE(I, TAPS)                                                                                       \
-    {                                                                                                             \
-        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
-        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
-        const T* in_ = (const T*)p.in[s_];                                                                        \
-        const int cs_ = p.in_cs[s_], co_ = p.in_co[s_] + chunk_ * KCH;                                            \
-        /* unconditional loads (out-of-image items read pixel 0 and are zeroed at commit): a guarded load   \
-           makes hipcc park the staging registers in scratch behind a vmcnt(0) each */                      \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it)                                                 \
-            a_reg[it] = *(const u32x4*)(in_ + (s_ ? a_pix1[it] : a_pix[it]) * cs_ + co_ + a_half[it] * EPS);      \
-        const char* wsrc_ = (const char*)p.w[s_] + ((long)chunk_ * (TAPS) * p.n_pad + n0) * 32;                   \
-        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
-            int idx = tid + it * 256;                                                                             \
-            idx = idx < (TAPS) * BN * 2 ? idx : (TAPS) * BN * 2 - 1;                                              \
-            const int tap = idx / (BN * 2), rem = idx % (BN * 2);                                                 \
-            b_reg[it] = *(const u32x4*)(wsrc_ + (long)tap * p.n_pad * 32 + rem * 16);                             \
-        }                                                                                                         \
-    }
-#define PSSR_COMMIT(I, TAPS)                                                                                      \
-    {                                                                                                             \
-        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
-        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
-        const bool pro_ = (s_ == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                          \
-        const bool gelu_ = (s_ == 0) && (p.prologue == PSSR_PRO_GELU);                                            \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            if (a_lds[it] >= 0) {                                                                                 \
-                u32x4 v = a_reg[it];                                                                              \
-                if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                          \
-                if (pro_ && a_ok[it]) {                                                                           \
-                    const int c0 = chunk_ * KCH + a_half[it] * EPS;                                               \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
-                        const float4 sc = *(const float4*)(p.pro_scale + c0 + e);                                 \
-                        const float4 sh = *(const float4*)(p.pro_shift + c0 + e);                                 \
-                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
-                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
-                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
-                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
-                    }                                                                                             \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                          \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                *(u32x4*)(As + a_lds[it]) = v;                                                                    \
-            }                                                                                                     \
-        }                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
-            const int idx = tid + it * 256;                                                                       \
-            if (idx < (TAPS) * BN * 2) *(u32x4*)(Bs + idx * 16) = b_reg[it];                                      \
-        }                                                                                                         \
-    }
-#define PSSR_COMPUTE(TAPS)                                                                                        \
-    {                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < (TAPS); ++t) {                                                      \
-            const int ky = ((TAPS) == 9) ? t / 3 : 1, kx = ((TAPS) == 9) ? t % 3 : 1;                             \
-            u32x4 af[C::MI], bf[C::NJ];                                                                           \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                \
-                const int pa = a_p0[mi] + ky * C::HW2 + kx;                                                       \
-                af[mi] = *(const u32x4*)(As + pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4));                            \
-            }                                                                                                     \
-            _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]); \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
-        }                                                                                                         \
-    }
-
-    // source 0 (TAPS0 taps) then the optional 1x1 source 1; the loads of the next chunk fly during the MFMAs
-    // split-K (p.ksplit > 1, single source): blockIdx.y multiplies chunks [cb, n0c) of its slice only
-    int cb = 0, n0c = p.nchunks[0];
-    if (p.ksplit > 1) {
-        const int per = (n0c + p.ksplit - 1) / p.ksplit;
-        cb = blockIdx.y * per;
-        n0c = cb + per < n0c ? cb + per : n0c;
-    }
-    if (cb < n0c) PSSR_ISSUE(cb, TAPS0)
-    for (int i = cb; i < n0c; ++i) {
-        PSSR_COMMIT(i, TAPS0)
-        __syncthreads();
-        if (i + 1 < n0c) PSSR_ISSUE(i + 1, TAPS0)
-        else if (i + 1 < total && p.ksplit <= 1) PSSR_ISSUE(i + 1, 1)
-        PSSR_COMPUTE(TAPS0)
-        __syncthreads();
-    }
-    for (int i = n0c; i < total && p.ksplit <= 1; ++i) {
-        PSSR_COMMIT(i, 1)
-        __syncthreads();
-        if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
-        PSSR_COMPUTE(1)
-        __syncthreads();
-    }
-#undef PSSR_ISSUE
-#undef PSSR_COMMIT
-#undef PSSR_COMPUTE
-
-    if (p.ksplit > 1) {
-        // raw accumulators of this K slice: ws[((block * ksplit + slice) * 16*MI*NJ + j) * 256 + tid] as float4 (coalesced)
-        float4* dst = (float4*)p.ws + ((long)blockIdx.x * p.ksplit + blockIdx.y) * (4 * C::MI * C::NJ) * 256 + tid;
-#pragma unroll
-        for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[((mi * C::NJ + nj) * 4 + q) * 256] = make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
-        return;
-    }
-    conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
-}
-
-// second pass of a split-K convolution: sum the K slices of a tile and run the ordinary epilogue
-template <typename T, int BN, int GEO>
-__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
-    using C = Cfg<BN, GEO>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
-    const int tn = bid % p.tiles_n;
-    int tmi = bid / p.tiles_n;
-    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
-    const int tile_y = tmi % p.tiles_y;
-    const int tile_i = tmi / p.tiles_y;
-    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
-    f32x16 acc[C::MI][C::NJ];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
-    for (int kz = 0; kz < p.ksplit; ++kz) {
-        const float4* src = (const float4*)p.ws + ((long)bid * p.ksplit + kz) * (4 * C::MI * C::NJ) * 256 + tid;
-#pragma unroll
-        for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = src[((mi * C::NJ + nj) * 4 + q) * 256];
-                    acc[mi][nj][4 * q] += v.x; acc[mi][nj][4 * q + 1] += v.y; acc[mi][nj][4 * q + 2] += v.z; acc[mi][nj][4 * q + 3] += v.w;
-                }
-    }
-    conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
-}
-
-// =================================================================================================================
-// Pipelined main loop ("v2") for layers that fill the chip with 256-pixel tiles: 16x16 output pixels x BN channels per
-// workgroup, 4 waves as WM x WN, each wave (256/WM) pixels x (BN/WN) channels = MI x NJ accumulator tiles (MI*NJ = 8).
-//   * the weight slices of the NEXT stage go global -> LDS by LDS-DMA (global_load_lds_dwordx4; the packed weight
-//     layout IS the LDS image), double-buffered, while the current stage is multiplied: no staging registers, no
-//     ds_write, one barrier per stage;
-//   * 3x3: a stage = one kernel row (3 taps) of one 32-byte channel chunk; the halo tile of a chunk is staged once
-//     (registers: BatchNorm+ReLU / GELU prologue, zero padding) and serves its 3 stages; it is requested at the first
-//     stage of the previous chunk and committed at its last, so the loads have 3 stages to land;
-//   * 1x1: a stage = 2 channel chunks, each with its own 256-pixel image;
-//   * LDS 45-48 KB and <= 256 registers: two workgroups per CU overlap each other's epilogue and pipeline fill.
-template <int BN, int TAPS> struct Cfg2 {
-    static constexpr int TWL = 4, THL = 4, TW = 16, TH = 16, NI = 1, MPIX = 256;
-    static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = HPI;
-    static constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
-    static constexpr int MI = MPIX / 32 / WM, NJ = BN / (32 * WN);
-    static constexpr int NSL = TAPS == 9 ? 9 : 2;                                  // weight slices per stage (3x3: a whole chunk)
-    static constexpr int A_PIX = TAPS == 9 ? HP : MPIX;                             // pixels of one staged image
-    static constexpr int A_IMGS = TAPS == 9 ? 1 : NSL;                              // images per stage buffer
-    static constexpr int A_BYTES = A_IMGS * A_PIX * 32, B_BYTES = NSL * BN * 32;
-    static constexpr int A_ITEMS = (2 * A_IMGS * A_PIX + 255) / 256;
-    static constexpr int B_PIECES = B_BYTES / 1024;                                 // 1-KiB LDS-DMA wave-instructions per stage
-    static constexpr int E_BYTES = WM * 32 * BN * 4, RED_BYTES = 4 * BN * 2 * 4;
-    static constexpr int RING = 2;                                                  // weight stages resident in LDS
-    static constexpr int MAIN_BYTES = 2 * A_BYTES + RING * B_BYTES;
-    static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-};
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
-template <typename T, int BN, int TAPS0>
-__global__ __launch_bounds__(256, 1) void conv_igemm2_kernel(const ConvArgs p) {
-    using C = Cfg2<BN, TAPS0>;
-    using X = TT<T>;
-    constexpr int EPS = X::EPS, KCH = X::KCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Abuf = smem;                               // [2][A_BYTES]
-    char* Bbuf = smem + 2 * C::A_BYTES;              // [RING][B_BYTES]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int h = lane >> 5, r = lane & 31;
-    const int bid = blockIdx.x;
-    const int tn = bid % p.tiles_n;
-    int tmi = bid / p.tiles_n;
-    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
-    const int tile_y = tmi % p.tiles_y;
-    const int img0 = tmi / p.tiles_y;
-    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, n0 = tn * BN;
-
-    // ---- staging descriptors of the input image(s)
-    long a_pix[C::A_ITEMS], a_pix1[C::A_ITEMS];
-    int a_lds[C::A_ITEMS], a_half[C::A_ITEMS], a_sub[C::A_ITEMS];
-    bool a_ok[C::A_ITEMS];
-#pragma unroll
-    for (int it = 0; it < C::A_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        const int half = idx & 1;
-        int pp = idx >> 1;
-        const int sub = (TAPS0 == 9) ? 0 : pp / C::A_PIX;      // 1x1: which chunk image of the stage
-        pp -= sub * C::A_PIX;
-        int gy, gx;
-        if constexpr (TAPS0 == 9) { gy = y0 + pp / C::HW2 - 1; gx = x0 + pp % C::HW2 - 1; }
-        else { gy = y0 + (pp >> C::TWL); gx = x0 + (pp & (C::TW - 1)); }
-        const bool in_range = idx < 2 * C::A_IMGS * C::A_PIX;
-        const bool inb = in_range && img0 < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_ok[it] = inb;
-        a_pix[it] = inb ? pix_index(img0, gy, gx, p.H, p.W, p.in0_blk) : 0;
-        a_pix1[it] = inb ? ((long)img0 * p.H + gy) * p.W + gx : 0;
-        a_lds[it] = in_range ? (sub * C::A_PIX * 32 + pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
-        a_half[it] = half;
-        a_sub[it] = sub;
-    }
-    int a_p0[C::MI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-        const int m = wm * C::MI * 32 + mi * 32 + r;
-        const int tx = m & (C::TW - 1), ty = m >> C::TWL;
-        a_p0[mi] = (TAPS0 == 9) ? ty * C::HW2 + tx : m;
-    }
-    int b_off[C::NJ];
-#pragma unroll
-    for (int nj = 0; nj < C::NJ; ++nj) {
-        const int n = wn * C::NJ * 32 + nj * 32 + r;
-        b_off[nj] = n * 32 + ((h ^ ((n >> 3) & 1)) << 4);
-    }
-    f32x16 acc[C::MI][C::NJ];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
-
-    const int n0c = p.nchunks[0], n1c = p.nchunks[1];
-    // stage -> (source, first chunk, first tap, slices).  3x3: 3 stages per source-0 chunk, then one 1-slice stage per
-    // source-1 chunk (centre tap of the same halo geometry).  1x1: NSL chunks per stage, single source.
-    const int nst = (TAPS0 == 9) ? n0c + n1c : (n0c + C::NSL - 1) / C::NSL;
-    u32x4 a_reg[C::A_ITEMS];
-
-#define V2_ISSUE_A(SRC, CHUNK)                                                                                    \
-    {                                                                                                             \
-        const T* in_ = (const T*)p.in[SRC];                                                                       \
-        const int cs_ = p.in_cs[SRC];                                                                             \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            int ch_ = (CHUNK) + a_sub[it];                                                                        \
-            if (TAPS0 != 9 && ch_ >= n0c) ch_ = n0c - 1;       /* odd chunk count: the last slice is not multiplied */ \
-            a_reg[it] = *(const u32x4*)(in_ + ((SRC) ? a_pix1[it] : a_pix[it]) * cs_ + p.in_co[SRC] + ch_ * KCH + a_half[it] * EPS); \
-        }                                                                                                         \
-    }
-#define V2_COMMIT_A(SRC, CHUNK, DST)                                                                              \
-    {                                                                                                             \
-        const bool pro_ = ((SRC) == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                       \
-        const bool gelu_ = ((SRC) == 0) && (p.prologue == PSSR_PRO_GELU);                                         \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            if (a_lds[it] >= 0) {                                                                                 \
-                u32x4 v = a_reg[it];                                                                              \
-                if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                                         \
-                if (pro_ && a_ok[it]) {                                                                           \
-                    int ch_ = (CHUNK) + a_sub[it];                                                                \
-                    if (TAPS0 != 9 && ch_ >= n0c) ch_ = n0c - 1;                                                  \
-                    const int c0 = ch_ * KCH + a_half[it] * EPS;                                                  \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
-                        const float4 sc = *(const float4*)(p.pro_scale + c0 + e);                                 \
-                        const float4 sh = *(const float4*)(p.pro_shift + c0 + e);                                 \
-                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
-                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
-                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
-                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
-                    }                                                                                             \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                if (gelu_) {                                                                                      \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                *(u32x4*)((DST) + a_lds[it]) = v;                                                                 \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // weight slices of stage S -> Bbuf[S & 1] by LDS-DMA: piece q = 1 KiB = 64 lanes x 16 B, linear in LDS and in the packed weights
-#define V2_ISSUE_B(S)                                                                                             \
-    {                                                                                                             \
-        const int s_ = (S);                                                                                       \
-        const bool src1_ = (TAPS0 == 9) && s_ >= n0c;                                                             \
-        const int chunk_ = (TAPS0 == 9) ? (src1_ ? s_ - n0c : s_) : s_ * C::NSL;                                  \
-        const int tap0_ = 0;                                                                                      \
-        const int taps_ = (TAPS0 == 9 && !src1_) ? 9 : 1;                                                         \
-        const char* wsrc_ = (const char*)p.w[src1_ ? 1 : 0];                                                      \
-        char* bdst_ = Bbuf + (s_ % C::RING) * C::B_BYTES;                                                         \
-        nb_issued = 0;                                                                                            \
-        constexpr int PPS_ = BN * 32 / 1024;                  /* pieces per slice */                              \
-        _Pragma("unroll") for (int j = 0; j < (C::B_PIECES + 3) / 4; ++j) {                                       \
-            const int q = wave + 4 * j;                                                                           \
-            const int sl = q / PPS_, pq = q % PPS_;                                                               \
-            int ck = chunk_, tp = tap0_;                                                                          \
-            if (TAPS0 == 9) tp += sl; else ck += sl;                                                              \
-            const bool live = q < C::B_PIECES && (TAPS0 == 9 ? (!src1_ || sl == 0) : ck < n0c);                   \
-            if (live) {                                                                                           \
-                const char* g_ = wsrc_ + (((long)ck * taps_ + tp) * p.n_pad + n0) * 32 + pq * 1024 + lane * 16;    \
-                __builtin_amdgcn_global_load_lds((glb_void_t*)g_, (lds_void_t*)(bdst_ + sl * BN * 32 + pq * 1024), 16, 0, 0); \
-                ++nb_issued;                                                                                      \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // one stage = NSLICES weight slices against the staged image.  The fragments of slice i+1 are requested before the MFMAs
-    // of slice i are issued (two register sets, compile-time indices after unrolling), so a wave that is alone on its SIMD
-    // keeps the LDS latency under its own matrix work.
-#define V2_FRAGS(SET, SL, AIMG, KY3, KX0)                                                                         \
-    {                                                                                                             \
-        _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                    \
-            int pa;                                                                                               \
-            if (TAPS0 == 9) pa = a_p0[mi] + ((KY3) ? ((SL) / 3) : 1) * C::HW2 + ((KY3) ? ((SL) % 3) : (KX0));     \
-            else pa = (SL) * C::A_PIX + a_p0[mi];                                                                 \
-            const int pin = (TAPS0 == 9) ? pa : a_p0[mi];                                                         \
-            af[SET][mi] = *(const u32x4*)((AIMG) + pa * 32 + ((h ^ ((pin >> 3) & 1)) << 4));                      \
-        }                                                                                                         \
-        _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[SET][nj] = *(const u32x4*)(bs_ + (SL) * BN * 32 + b_off[nj]); \
-    }
-#define V2_COMPUTE(BSTAGE, AIMG, KY3, NSLICES, KX0)                                                               \
-    {                                                                                                             \
-        const char* bs_ = Bbuf + (BSTAGE) * C::B_BYTES;                                                           \
-        u32x4 af[2][C::MI], bf[2][C::NJ];                                                                         \
-        V2_FRAGS(0, 0, AIMG, KY3, KX0)                                                                            \
-        _Pragma("unroll") for (int sl = 0; sl < (NSLICES); ++sl) {                                                \
-            if (sl + 1 < (NSLICES)) V2_FRAGS((sl + 1) & 1, sl + 1, AIMG, KY3, KX0)                                \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[sl & 1][mi], bf[sl & 1][nj]); \
-            /* pin the interleave: one fragment read of the NEXT slice behind each MFMA of this one (left alone, the  \
-               scheduler minimises registers and serialises read -> wait -> 2 MFMAs) */                             \
-            if (sl + 1 < (NSLICES)) {                                                                             \
-                _Pragma("unroll") for (int q = 0; q < C::MI + C::NJ; ++q) {                                       \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-                }                                                                                                 \
-                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ - (C::MI + C::NJ), 0);                  \
-            } else {                                                                                              \
-                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ, 0);                                    \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-
-    int abuf = 0;
-    int nb_issued = 0;          // LDS-DMA instructions this wave issued for the youngest weight stage
-    // wait until only this wave's youngest `n` vector-memory operations (= its DMAs of the stage after next) are in flight
-#define V2_WAIT_BUT(N)                                                                                            \
-    { const int n_ = (N);                                                                                         \
-      if (n_ >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                               \
-      else if (n_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
-      else if (n_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                          \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    if constexpr (TAPS0 == 9) {
-        // stage = one 32-byte channel chunk of source 0 (9 taps) or one chunk of the 1x1 source 1 (centre tap of its halo
-        // image); weights and image of stage s+1 are requested at the start of stage s (LDS-DMA / registers) and must have
-        // landed at its end: one wait + one barrier per stage
-        const int nimg = n0c + n1c;
-        if (n0c > 0) { V2_ISSUE_A(0, 0) } else { V2_ISSUE_A(1, 0) }
-        V2_ISSUE_B(0)
-        if (n0c > 0) { V2_COMMIT_A(0, 0, Abuf) } else { V2_COMMIT_A(1, 0, Abuf) }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int c = 0; c < nimg; ++c) {
-            const bool more = c + 1 < nimg;
-            const int nsrc = (c + 1 >= n0c) ? 1 : 0, nchunk = nsrc ? c + 1 - n0c : c + 1;
-            if (more) {
-                if (nsrc) V2_ISSUE_A(1, nchunk) else V2_ISSUE_A(0, nchunk)
-                V2_ISSUE_B(c + 1)
-            }
-            if (c < n0c) V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 1, 9, 0)
-            else V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 0, 1, 1)
-            if (more) {
-                if (nsrc) V2_COMMIT_A(1, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES) else V2_COMMIT_A(0, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES)
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            abuf ^= 1;
-        }
-    } else {
-        V2_ISSUE_B(0)
-        V2_ISSUE_A(0, 0)
-        V2_COMMIT_A(0, 0, Abuf)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int s = 0; s < nst; ++s) {
-            const bool more = s + 1 < nst;
-            if (more) { V2_ISSUE_B(s + 1) V2_ISSUE_A(0, (s + 1) * C::NSL) }
-            if (s * C::NSL + 1 < n0c) V2_COMPUTE(s & 1, Abuf + (s & 1) * C::A_BYTES, 0, 2, 0)
-            else V2_COMPUTE(s & 1, Abuf + (s & 1) * C::A_BYTES, 0, 1, 0)
-            if (more) V2_COMMIT_A(0, (s + 1) * C::NSL, Abuf + ((s + 1) & 1) * C::A_BYTES)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-#undef V2_WAIT_BUT
-#undef V2_FRAGS
-#undef V2_ISSUE_A
-#undef V2_COMMIT_A
-#undef V2_ISSUE_B
-#undef V2_COMPUTE
-    __syncthreads();
-    conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
-}
-
-template <typename T, int BN, int TAPS0>
-int launch2_t(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg2<BN, TAPS0>;
-    ConvArgs p = a;
-    p.tiles_x = cdiv(a.W, C::TW);
-    p.tiles_y = cdiv(a.H, C::TH);
-    p.tiles_n = cdiv(a.cout, BN);
-    const long blocks = (long)p.tiles_x * p.tiles_y * a.N * p.tiles_n;
-    PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<T, BN, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, BN, TAPS0>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
-
-// the pipelined kernel needs >= 16x16 images and enough 256-pixel tiles to fill the chip (PSSR_IGEMM_V2=0 disables it)
-// 0 (default): off; 1: for 3x3 layers whose 256-pixel tiles fill the chip twice over; 2: whenever the shape allows (tests).
-// Round-1 measurement: correct (tests/test_gpu_conv.py runs every case with mode 2) but slower than the 128-pixel
-// main loop, because hipcc serialises each fragment ds_read behind an lgkmcnt(0) at this register pressure
-// (128 accumulators + descriptors at 1-2 waves per SIMD); it needs hand-placed fragment reads before it pays.
-int g_v2_mode = -1;
-
-template <typename T, int BN>
-bool use_v2(const ConvArgs& a) {
-    if (g_v2_mode < 0) { const char* e = getenv("PSSR_IGEMM_V2"); g_v2_mode = e ? atoi(e) : 0; }
-    if (!g_v2_mode || a.W < 16 || a.H < 16 || a.ksplit < 0) return false;      // (ksplit < 0: workspace-size query)
-    if (a.taps[0] == 1 && a.nchunks[1] != 0) return false;
-    if (g_v2_mode == 2) return true;
-    const long blocks = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.N * cdiv(a.cout, BN);
-    return a.taps[0] == 9 && blocks >= 512;
-}
-
-template <typename T, int BN, int GEO, int TAPS0>
-int launch_t(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg<BN, GEO>;
-    ConvArgs p = a;
-    p.tiles_x = cdiv(a.W, C::TW);
-    p.tiles_y = cdiv(a.H, C::TH);
-    p.tiles_n = cdiv(a.cout, BN);
-    const long blocks = (long)p.tiles_x * p.tiles_y * cdiv(a.N, C::NI) * p.tiles_n;
-    PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
-    // split-K when the tiles do not fill the chip and K is long: ~384 workgroups, >= 4 chunks per slice, <= 8 slices
-    int ksplit = 1;
-    if (BN >= 64 && a.nchunks[1] == 0 && a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
-        ksplit = (int)((384 + blocks - 1) / blocks);
-        if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
-        if (ksplit > 8) ksplit = 8;
-    }
-    const long ws_bytes = ksplit > 1 ? blocks * ksplit * (long)(64 * C::MI * C::NJ) * 256 : 0;
-    if (a.ksplit < 0) { *(long*)a.ws = ws_bytes; return PSSR_OK; }          // workspace-size query
-    if (ksplit > 1 && (a.ws == nullptr || (long)a.ksplit * 1024 < ws_bytes)) ksplit = 1;   // caller gave no (or too small a) workspace
-    p.ksplit = ksplit;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_splitk_finish_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES, stream, p);
-    if (ksplit > 1)
-        hipLaunchKernelGGL((conv_splitk_finish_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
-
-template <typename T, int BN, int GEO>
-int launch(const ConvArgs& a, hipStream_t s) {
-    return a.taps[0] == 9 ? launch_t<T, BN, GEO, 9>(a, s) : launch_t<T, BN, GEO, 1>(a, s);
-}
-
-template <typename T, int BN>
-int launch_geo(const ConvArgs& a, hipStream_t s) {
-    const int w = a.W;
-    if (w > 8) return launch<T, BN, 0>(a, s);
-    if (w > 4) return launch<T, BN, 1>(a, s);
-    if (w > 2) return launch<T, BN, 2>(a, s);
-    if (w > 1) return launch<T, BN, 3>(a, s);
-    return launch<T, BN, 4>(a, s);
-}
-
-template <typename T>
-int launch_bn(const ConvArgs& a, hipStream_t s) {
-    if (a.cout > 64) {
-        if (use_v2<T, 128>(a)) return a.taps[0] == 9 ? launch2_t<T, 128, 9>(a, s) : launch2_t<T, 128, 1>(a, s);
-        return launch_geo<T, 128>(a, s);
-    }
-    if (a.cout > 32) {
-        if (use_v2<T, 64>(a)) return a.taps[0] == 9 ? launch2_t<T, 64, 9>(a, s) : launch2_t<T, 64, 1>(a, s);
-        return launch_geo<T, 64>(a, s);
-    }
-    return launch_geo<T, 32>(a, s);
-}
-
-}  // namespace
+using pssr_conv::ConvArgs;
+int pssr_conv::g_v2_mode = -1;
+using pssr_conv::g_v2_mode;
 
 extern "C" int pssr_conv2d_pipeline_mode(int mode) {
     const int old = g_v2_mode;
@@ -832,11 +77,14 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     a.in0_blk = d->in0_blk; a.out_blk = d->out_blk; a.aux_blk = d->aux_blk;
     a.out_scale = d->out_scale; a.out_shift = d->out_shift;
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
+    a.epi8 = esz == 2 && d->epilogue != PSSR_EPI_FINAL && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 &&
+             (d->epilogue == PSSR_EPI_STORE || (d->aux_coff % 8 == 0 && d->aux_cstride % 8 == 0));
+    { const char* e_ = getenv("PSSR_CONV_EPI8"); if (e_ && atoi(e_) == 0) a.epi8 = 0; }
     long ws_query = 0;
     if (query_ws) { a.ksplit = -1; a.ws = (float*)&ws_query; }
     else { a.ws = (float*)d->workspace; a.ksplit = d->workspace ? (int)(d->workspace_bytes / 1024) : 0; }
     hipStream_t s = (hipStream_t)stream;
-    const int rc = d->dtype == PSSR_BF16 ? launch_bn<bf16_t>(a, s) : d->dtype == PSSR_F16 ? launch_bn<f16_t>(a, s) : launch_bn<float>(a, s);
+    const int rc = d->dtype == PSSR_BF16 ? pssr_conv::launch_bf16(a, s) : d->dtype == PSSR_F16 ? pssr_conv::launch_f16(a, s) : pssr_conv::launch_f32(a, s);
     if (query_ws) *query_ws = ws_query;
     return rc;
 }

@@ -1,0 +1,4 @@
+// bf16_t build of the implicit-GEMM convolution (see conv_igemm_impl.h)
+#include "conv_igemm_impl.h"
+
+int pssr_conv::launch_bf16(const ConvArgs& a, hipStream_t s) { return launch_bn<bf16_t>(a, s); }

@@ -219,7 +219,9 @@ def test_fp16_three_channel_vs_oracle():
     scaler.scale(loss).backward()
     grads = {n: p.grad.detach().clone().cpu().double() / scaler.scale_value for n, p in model.named_parameters()}
     p64 = {k: (v.double().requires_grad_(True) if "running" not in k else v.double()) if v.dtype.is_floating_point else v for k, v in sd0.items()}
-    y64, _ = M.resunet_forward(x.double(), p64, 3, 3, 4, train=True)
+    # the f64 graph takes the ReLU decisions the fp16 path took: 16-bit storage flips many near-zero decisions of an
+    # untrained net, and a flipped decision is a different (equally valid) subgradient, not an arithmetic error
+    y64, _ = M.resunet_forward(x.double(), p64, 3, 3, 4, train=True, masks=engine_relu_masks(model))
     l64 = LR.ssim_loss(y64 / 255, hr.double() / 255, mix=0.8)
     assert abs(loss.item() - l64.item()) < 2e-3
     l64.backward()
@@ -228,7 +230,7 @@ def test_fp16_three_channel_vs_oracle():
         a, b = a.flatten(), b.flatten()
         return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
 
-    low = [(n, cos(grads[n], p64[n].grad)) for n in grads if p64[n].grad.abs().max() > 1e-9 and cos(grads[n], p64[n].grad) < 0.9]     # 16-bit storage on an untrained, ReLU-mask-heavy net (cf. test_bf16_close_to_f32)
+    low = [(n, cos(grads[n], p64[n].grad)) for n in grads if p64[n].grad.abs().max() > 1e-9 and cos(grads[n], p64[n].grad) < 0.97]
     assert not low, low
     before = [p.detach().clone() for p in model.parameters()]
     assert scaler.step(opt, list(model.parameters())) is True        # finite gradients: the step is taken, unscaled
