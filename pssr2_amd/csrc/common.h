@@ -13,6 +13,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging register (native vector: stays in VGPRs)
 
 // A "slot" is 16 bytes of consecutive channels of one pixel: 8 bf16 or 4 f32.  Every tile in
@@ -31,6 +35,13 @@ template <> struct TT<float> {
         return r;
     }
     static __device__ __forceinline__ float round(float v) { return v; }
+    // relu(x * scale + shift) of one slot (the BatchNorm + ReLU prologue of the loaders)
+    static __device__ __forceinline__ u32x4 bn_relu(const u32x4& raw, const float* sc, const float* sh) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __float_as_uint(fmaxf(fmaf(__uint_as_float(raw[i]), sc[i], sh[i]), 0.f));
+        return o;
+    }
     // 32x32 tile, K = one slot per lane half: 4 x v_mfma_f32_32x32x2_f32 (exact f32 fma chain)
     static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[0]), __uint_as_float(b[0]), c, 0, 0, 0);
@@ -51,13 +62,30 @@ template <> struct TT<bf16_t> {
             f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    static __device__ __forceinline__ u32x4 pack(const float* f) {
-        bf16x8 v;
+    static __device__ __forceinline__ u32x4 pack(const float* f) {      // pairwise: one v_cvt_pk_bf16_f32 per dword
+        u32x4 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
-        return __builtin_bit_cast(u32x4, v);
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 y = {f[2 * i], f[2 * i + 1]};
+            o[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y, bf16x2));
+        }
+        return o;
     }
     static __device__ __forceinline__ float round(float v) { return (float)(bf16_t)v; }
+    // relu(x * scale + shift) of one slot, rounded to bf16: packed f32 fma, packed convert, ReLU as a signed 16-bit max
+    // with 0 on the rounded values (same result as rounding relu(.) since rounding keeps the sign)
+    static __device__ __forceinline__ u32x4 bn_relu(const u32x4& raw, const float* sc, const float* sh) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 x = {__uint_as_float(raw[i] << 16), __uint_as_float(raw[i] & 0xffff0000u)};
+            const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, t = {sh[2 * i], sh[2 * i + 1]};
+            const f32x2 y = __builtin_elementwise_fma(x, s, t);
+            const s16x2 z = {0, 0};
+            o[i] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(y, bf16x2)), z));
+        }
+        return o;
+    }
     // one v_mfma_f32_32x32x16_bf16
     static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -80,6 +108,19 @@ template <> struct TT<f16_t> {      // fp16 storage, f32 accumulate (config "fp1
         return __builtin_bit_cast(u32x4, v);
     }
     static __device__ __forceinline__ float round(float v) { return (float)(f16_t)v; }
+    static __device__ __forceinline__ u32x4 bn_relu(const u32x4& raw, const float* sc, const float* sh) {
+        const f16x8 v = __builtin_bit_cast(f16x8, raw);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 x = {(float)v[2 * i], (float)v[2 * i + 1]};
+            const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, t = {sh[2 * i], sh[2 * i + 1]};
+            const f32x2 y = __builtin_elementwise_fma(x, s, t);
+            const s16x2 z = {0, 0};
+            o[i] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(y, f16x2)), z));
+        }
+        return o;
+    }
     // one v_mfma_f32_32x32x16_f16
     static __device__ __forceinline__ void mma(f32x16& c, const u32x4& a, const u32x4& b) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

@@ -29,6 +29,8 @@ namespace {
 
 
 
+constexpr int PRO_LDS_MAX = 4096 * 8;     // prologue table: scale + shift (f32) of up to 4096 input channels
+
 template <int GEO> struct Geo;
 template <> struct Geo<0> { static constexpr int TWL = 4, THL = 3; };   // 8 x 16, 1 image
 template <> struct Geo<1> { static constexpr int TWL = 3, THL = 3; };   // 8 x 8,  2 images
@@ -335,32 +337,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int tile_i = tmi / p.tiles_y;
     const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
 
-    // ---- per-thread staging descriptors for the input halo (same pixels for every chunk)
-    long a_pix[C::A_ITEMS], a_pix1[C::A_ITEMS];   // source 0 (possibly blocked order); source 1 is always plain NHWC
+    // ---- per-thread staging descriptors for the input halo (same pixels for every chunk).  All addressing that does
+    // not change from chunk to chunk lives in 32-bit buffer offsets computed once: the per-chunk part of every load
+    // is a scalar offset, so the main loop issues no address arithmetic on the vector ALU (measured before this:
+    // 7.5 vector instructions per MFMA, i.e. the VALU port, not the MFMA pipe, set the pace).
+    const long img_base = (long)img0 * p.H * p.W;                  // first pixel of this tile's first image
+    constexpr int ESZ = (int)sizeof(T);
+    unsigned a_off0[C::A_ITEMS], a_off1[C::A_ITEMS];               // byte offsets from that pixel (source 0 may be in blocked order)
     int a_lds[C::A_ITEMS];
     bool a_ok[C::A_ITEMS];
-    int a_half[C::A_ITEMS];
+    const int half = tid & 1;                                      // (tid + it * 256) & 1: the same 16-byte half for every item
 #pragma unroll
     for (int it = 0; it < C::A_ITEMS; ++it) {
         const int idx = tid + it * 256;
-        const int pp = idx >> 1, half = idx & 1;
+        const int pp = idx >> 1;
         const int img = pp / C::HPI, rem = pp % C::HPI;
         const int hy = rem / C::HW2, hx = rem % C::HW2;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1, gi = img0 + img;
         const bool inb = (idx < 2 * C::HP) && gi < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         a_ok[it] = inb;
-        a_pix[it] = inb ? pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) : 0;
-        a_pix1[it] = inb ? ((long)gi * p.H + gy) * p.W + gx : 0;
+        a_off0[it] = inb ? (unsigned)((pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) - img_base) * p.in_cs[0] * ESZ + half * 16) : 0u;
+        a_off1[it] = inb ? (unsigned)(((long)img * p.H + gy) * p.W + gx) * (unsigned)(p.in_cs[1] * ESZ) + half * 16 : 0u;
         a_lds[it] = (idx < 2 * C::HP) ? (pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
-        a_half[it] = half;
     }
-    // ---- fragment read bases
-    int a_p0[C::MI];
+    // buffer resources (wave-uniform by construction: kernel arguments and blockIdx only)
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.in[0] + (img_base * p.in_cs[0] + p.in_co[0]) * ESZ), 0, (int)0xfffffff0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.in[1] + (img_base * p.in_cs[1] + p.in_co[1]) * ESZ), 0, (int)0xfffffff0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w[0] + (long)n0 * 32), 0, (int)0xfffffff0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w[1] + (long)n0 * 32), 0, (int)0xfffffff0u, 0x00020000);
+    // weights: piece idx = tid + it * 256 of the [taps][BN][32 B] slice of a chunk; PT pieces per tap, TPI taps per item
+    constexpr int PT = BN * 2, TPI = 256 / PT;
+    const int tap_stride = p.n_pad * 32;
+    const unsigned b_voff = (unsigned)((tid / PT) * tap_stride + (tid % PT) * 16);
+    const unsigned b_voff_tail = (unsigned)((tid % PT) * 16);      // partial last item: lanes past the slice re-read its first tap (never written)
+    // ---- fragment read addresses (loop-invariant: one per accumulator row tile and tap)
+    constexpr int CT = (TAPS0 == 9) ? 4 : 0;                       // index of the centre tap
+    int a_rd[C::MI][TAPS0];
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi) {
         const int m = wm * C::MI * 32 + mi * 32 + r;
         const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
-        a_p0[mi] = img * C::HPI + ty * C::HW2 + tx;
+        const int p0 = img * C::HPI + ty * C::HW2 + tx;
+#pragma unroll
+        for (int t = 0; t < TAPS0; ++t) {
+            const int ky = (TAPS0 == 9) ? t / 3 : 1, kx = (TAPS0 == 9) ? t % 3 : 1;
+            const int pa = p0 + ky * C::HW2 + kx;
+            a_rd[mi][t] = pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4);
+        }
     }
     int b_off[C::NJ];
 #pragma unroll
@@ -381,72 +406,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     u32x4 a_reg[C::A_ITEMS];
     u32x4 b_reg[C::B_ITEMS];
 
+    // BatchNorm prologue coefficients of source 0 live in LDS behind the tiles, one 32-byte-chunk half after the other:
+    // [chunk][half][scale x EPS | shift x EPS], so that a thread's 2*EPS coefficients of a chunk are 4 (bf16) / 2 (f32)
+    // 16-byte LDS reads at constant offsets from one address
+    float* const tab = (float*)(smem + C::LDS_BYTES);
+    if (p.prologue == PSSR_PRO_BN_RELU) {
+        const int cin0 = p.nchunks[0] * KCH;
+        for (int i = tid; i < cin0; i += 256) {
+            const int c = i / KCH, w_ = i % KCH;
+            float* q = tab + ((c * 2 + w_ / EPS) * 2) * EPS + (w_ % EPS);
+            q[0] = p.pro_scale[i]; q[EPS] = p.pro_shift[i];
+        }
+        __syncthreads();
+    }
+    const float* const tab_t = tab + half * 2 * EPS;
+
     // NB: the three phases are macros, not lambdas: with lambdas hipcc keeps a_reg/b_reg in scratch.
-#define PSSR_ISSUE(I, TAPS)                                                                                       \
+    // S = source (0: TAPS taps, 1: the 1x1 second source), both compile-time
+#define PSSR_ISSUE(S, CHUNK, TAPS)                                                                                \
     {                                                                                                             \
-        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
-        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
-        const T* in_ = (const T*)p.in[s_];                                                                        \
-        const int cs_ = p.in_cs[s_], co_ = p.in_co[s_] + chunk_ * KCH;                                            \
-        /* unconditional loads (out-of-image items read pixel 0 and are zeroed at commit): a guarded load   \
-           makes hipcc park the staging registers in scratch behind a vmcnt(0) each */                      \
+        /* unconditional loads (out-of-image items read pixel 0 and are zeroed at commit) */                      \
+        const int asoff_ = (CHUNK) * 32;                                                                          \
         _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it)                                                 \
-            a_reg[it] = *(const u32x4*)(in_ + (s_ ? a_pix1[it] : a_pix[it]) * cs_ + co_ + a_half[it] * EPS);      \
-        const char* wsrc_ = (const char*)p.w[s_] + ((long)chunk_ * (TAPS) * p.n_pad + n0) * 32;                   \
-        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
-            int idx = tid + it * 256;                                                                             \
-            idx = idx < (TAPS) * BN * 2 ? idx : (TAPS) * BN * 2 - 1;                                              \
-            const int tap = idx / (BN * 2), rem = idx % (BN * 2);                                                 \
-            b_reg[it] = *(const u32x4*)(wsrc_ + (long)tap * p.n_pad * 32 + rem * 16);                             \
+            a_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128((S) ? ra1 : ra0, (int)((S) ? a_off1[it] : a_off0[it]), asoff_, 0)); \
+        const int wsoff_ = (CHUNK) * (TAPS) * tap_stride;                                                         \
+        constexpr int NB_ = ((TAPS) * PT + 255) / 256;                                                            \
+        _Pragma("unroll") for (int it = 0; it < NB_; ++it) {                                                      \
+            const bool full_ = (it + 1) * 256 <= (TAPS) * PT;                                                     \
+            b_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128((S) ? rw1 : rw0, (int)(full_ ? b_voff : b_voff_tail), wsoff_ + it * TPI * tap_stride, 0)); \
         }                                                                                                         \
     }
-#define PSSR_COMMIT(I, TAPS)                                                                                      \
+#define PSSR_COMMIT(S, CHUNK, TAPS)                                                                               \
     {                                                                                                             \
-        const int s_ = ((I) >= p.nchunks[0]) ? 1 : 0;                                                             \
-        const int chunk_ = s_ ? (I) - p.nchunks[0] : (I);                                                         \
-        const bool pro_ = (s_ == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                          \
-        const bool gelu_ = (s_ == 0) && (p.prologue == PSSR_PRO_GELU);                                            \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            if (a_lds[it] >= 0) {                                                                                 \
-                u32x4 v = a_reg[it];                                                                              \
-                if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                          \
-                if (pro_ && a_ok[it]) {                                                                           \
-                    const int c0 = chunk_ * KCH + a_half[it] * EPS;                                               \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
-                        const float4 sc = *(const float4*)(p.pro_scale + c0 + e);                                 \
-                        const float4 sh = *(const float4*)(p.pro_shift + c0 + e);                                 \
-                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
-                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
-                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
-                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
+        const bool pro_ = ((S) == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                         \
+        const bool gelu_ = ((S) == 0) && (p.prologue == PSSR_PRO_GELU);                                           \
+        if (pro_) {                                                                                               \
+            float tsc_[EPS], tsh_[EPS];                                                                           \
+            const float* tq_ = tab_t + (CHUNK) * (4 * EPS);                                                       \
+            _Pragma("unroll") for (int e = 0; e < EPS; e += 4) { load4(tq_ + e, tsc_ + e); load4(tq_ + EPS + e, tsh_ + e); } \
+            _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                           \
+                if (a_lds[it] >= 0) {                                                                             \
+                    u32x4 v = X::bn_relu(a_reg[it], tsc_, tsh_);                                                  \
+                    if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                                     \
+                    *(u32x4*)(As + a_lds[it]) = v;                                                                \
+                }                                                                                                 \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                           \
+                if (a_lds[it] >= 0) {                                                                             \
+                    u32x4 v = a_reg[it];                                                                          \
+                    if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                                     \
+                    if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                      \
+                        float f[EPS];                                                                             \
+                        X::unpack(v, f);                                                                          \
+                        _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                      \
+                        v = X::pack(f);                                                                           \
                     }                                                                                             \
-                    v = X::pack(f);                                                                               \
+                    *(u32x4*)(As + a_lds[it]) = v;                                                                \
                 }                                                                                                 \
-                if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                          \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                *(u32x4*)(As + a_lds[it]) = v;                                                                    \
             }                                                                                                     \
         }                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < C::B_ITEMS; ++it) {                                               \
-            const int idx = tid + it * 256;                                                                       \
-            if (idx < (TAPS) * BN * 2) *(u32x4*)(Bs + idx * 16) = b_reg[it];                                      \
+        constexpr int NB_ = ((TAPS) * PT + 255) / 256;                                                            \
+        _Pragma("unroll") for (int it = 0; it < NB_; ++it) {                                                      \
+            const bool full_ = (it + 1) * 256 <= (TAPS) * PT;                                                     \
+            if (full_ || tid < (TAPS) * PT - it * 256) *(u32x4*)(Bs + tid * 16 + it * 4096) = b_reg[it];          \
         }                                                                                                         \
     }
 #define PSSR_COMPUTE(TAPS)                                                                                        \
     {                                                                                                             \
         _Pragma("unroll") for (int t = 0; t < (TAPS); ++t) {                                                      \
-            const int ky = ((TAPS) == 9) ? t / 3 : 1, kx = ((TAPS) == 9) ? t % 3 : 1;                             \
             u32x4 af[C::MI], bf[C::NJ];                                                                           \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                \
-                const int pa = a_p0[mi] + ky * C::HW2 + kx;                                                       \
-                af[mi] = *(const u32x4*)(As + pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4));                            \
-            }                                                                                                     \
+            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
+                af[mi] = *(const u32x4*)(As + a_rd[mi][(TAPS) == TAPS0 ? t : CT]);                                \
             _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]); \
             _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
                 _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
@@ -461,21 +492,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         cb = blockIdx.y * per;
         n0c = cb + per < n0c ? cb + per : n0c;
     }
-    if (cb < n0c) PSSR_ISSUE(cb, TAPS0)
+    const bool second = p.nchunks[1] > 0 && p.ksplit <= 1;
+    if (cb < n0c) PSSR_ISSUE(0, cb, TAPS0)
     for (int i = cb; i < n0c; ++i) {
-        PSSR_COMMIT(i, TAPS0)
+        PSSR_COMMIT(0, i, TAPS0)
         __syncthreads();
-        if (i + 1 < n0c) PSSR_ISSUE(i + 1, TAPS0)
-        else if (i + 1 < total && p.ksplit <= 1) PSSR_ISSUE(i + 1, 1)
+        if (i + 1 < n0c) PSSR_ISSUE(0, i + 1, TAPS0)
+        else if (second) PSSR_ISSUE(1, 0, 1)
         PSSR_COMPUTE(TAPS0)
         __syncthreads();
     }
-    for (int i = n0c; i < total && p.ksplit <= 1; ++i) {
-        PSSR_COMMIT(i, 1)
-        __syncthreads();
-        if (i + 1 < total) PSSR_ISSUE(i + 1, 1)
-        PSSR_COMPUTE(1)
-        __syncthreads();
+    if (second) {
+        for (int i = 0; i < p.nchunks[1]; ++i) {
+            PSSR_COMMIT(1, i, 1)
+            __syncthreads();
+            if (i + 1 < p.nchunks[1]) PSSR_ISSUE(1, i + 1, 1)
+            PSSR_COMPUTE(1)
+            __syncthreads();
+        }
     }
 #undef PSSR_ISSUE
 #undef PSSR_COMMIT
@@ -850,17 +884,19 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
         if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
         if (ksplit > 8) ksplit = 8;
     }
+    const int pro_lds = a.prologue == PSSR_PRO_BN_RELU ? a.nchunks[0] * TT<T>::KCH * 8 : 0;     // prologue table behind the tiles
+    PSSR_CHECK(pro_lds <= PRO_LDS_MAX, PSSR_ERR_UNSUPPORTED, "conv2d: BatchNorm prologue over %d input channels", a.nchunks[0] * TT<T>::KCH);
     const long ws_bytes = ksplit > 1 ? blocks * ksplit * (long)(64 * C::MI * C::NJ) * 256 : 0;
     if (a.ksplit < 0) { *(long*)a.ws = ws_bytes; return PSSR_OK; }          // workspace-size query
     if (ksplit > 1 && (a.ws == nullptr || (long)a.ksplit * 1024 < ws_bytes)) ksplit = 1;   // caller gave no (or too small a) workspace
     p.ksplit = ksplit;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, GEO, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + PRO_LDS_MAX);
         (void)hipFuncSetAttribute((const void*)conv_splitk_finish_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, GEO, TAPS0>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds, stream, p);
     if (ksplit > 1)
         hipLaunchKernelGGL((conv_splitk_finish_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
     PSSR_LAUNCH_CHECK();

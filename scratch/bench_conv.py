@@ -30,7 +30,8 @@ for name, H, W, ci, co, taps in layers:
     if which in ("all", "fwd"):
         t = timeit(lambda: ops.conv2d(x, ci, pw, out, co, n=N, h=H, w=W, bias=bias))
         t2 = timeit(lambda: ops.conv2d(x, ci, pw, out, co, n=N, h=H, w=W, bias=bias, pro_scale=sc, pro_shift=sh, flags=L.FLAG_STATS, stats=stats))
-        print(f"{name:20s} fwd plain {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s | +prologue+stats {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s")
+        t3 = timeit(lambda: ops.conv2d(x, ci, pw, out, co, n=N, h=H, w=W, bias=bias, pro_scale=sc, pro_shift=sh))
+        print(f"{name:20s} fwd plain {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s | +prologue {t3*1e3:8.1f} us | +prologue+stats {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s")
     if which in ("all", "wgrad") and co >= 16:
         dy = torch.randn(N, H, W, co, device="cuda").to(dt)
         dwp = torch.zeros(co, taps, ci, device="cuda")
