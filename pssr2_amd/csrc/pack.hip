@@ -48,41 +48,38 @@ struct PackMap {
     }
 };
 
+// one 16-byte slot (EPS consecutive K positions of one (chunk, tap, n)) per thread: a single 16-byte store
 template <typename T>
-__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed, PackMap m, int k_pad, int n_pad, long total) {
+__device__ __forceinline__ void pack_slots(const float* __restrict__ w, T* __restrict__ packed, const PackMap& m, int k_pad, int n_pad) {
     constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int e = i % EPS;
-        long t = i / EPS;
+    const long slots = (long)m.taps * k_pad * n_pad / EPS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < slots; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
         const int slotpos = t % 2; t /= 2;
         const int n = t % n_pad; t /= n_pad;
         const int tap = t % m.taps;
         const int chunk = t / m.taps;
         const int slot = slotpos ^ ((n >> 3) & 1);
-        const int k = chunk * KCH + slot * EPS + e;
-        const long s = m.src_index(k, tap, n);
-        packed[i] = s >= 0 ? (T)w[s] : (T)0.f;
+        const int k0 = chunk * KCH + slot * EPS;
+        float f[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) {
+            const long s = m.src_index(k0 + e, tap, n);
+            f[e] = s >= 0 ? w[s] : 0.f;
+        }
+        *(u32x4*)(packed + i * EPS) = TT<T>::pack(f);
     }
+}
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed, PackMap m, int k_pad, int n_pad, long total) {
+    pack_slots<T>(w, packed, m, k_pad, n_pad);
 }
 
 // every weight of a model in ONE launch: blockIdx.y selects the item (a training step re-packs ~100 weights)
 template <typename T>
 __device__ __forceinline__ void pack_item(const pssr_pack_item& it, const PackMap& m) {
-    constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
-    const long total = (long)m.taps * it.k_pad * it.n_pad;
-    T* packed = (T*)it.packed;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int e = i % EPS;
-        long t = i / EPS;
-        const int slotpos = t % 2; t /= 2;
-        const int n = t % it.n_pad; t /= it.n_pad;
-        const int tap = t % m.taps;
-        const int chunk = t / m.taps;
-        const int slot = slotpos ^ ((n >> 3) & 1);
-        const int k = chunk * KCH + slot * EPS + e;
-        const long s = m.src_index(k, tap, n);
-        packed[i] = s >= 0 ? (T)it.w[s] : (T)0.f;
-    }
+    pack_slots<T>(it.w, (T*)it.packed, m, it.k_pad, it.n_pad);
 }
 
 __global__ void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
@@ -98,17 +95,91 @@ __global__ void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
 // (the destination is zeroed by `unpack_zero_kernel` first unless the caller accumulates into it).
 __global__ void unpack_kernel(const float* __restrict__ dwp, int parts, long part_stride, float* __restrict__ dw, PackMap m, int k_pad,
                               int accumulate, long total) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = i % k_pad;
-        long t = i / k_pad;
+    // 4 consecutive k per thread (k_pad is a multiple of 16): 16-byte loads, 4 parts in flight
+    const int kq = k_pad >> 2;
+    for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < (total >> 2); i4 += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i4 % kq) * 4;
+        long t = i4 / kq;
         const int tap = t % m.taps;
         const int n = t / m.taps;
-        const long s = m.src_index(k, tap, n);
-        if (s < 0) continue;
-        float v = 0.f;
-        for (int q = blockIdx.y; q < parts; q += gridDim.y) v += dwp[q * part_stride + i];
-        if (gridDim.y > 1) atomicAdd(dw + s, v);
-        else dw[s] = accumulate ? dw[s] + v : v;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = dwp + i4 * 4;
+        int q = blockIdx.y;
+        for (; q + 3 * (int)gridDim.y < parts; q += 4 * gridDim.y) {
+            const float4 a = *(const float4*)(src + (long)q * part_stride);
+            const float4 b = *(const float4*)(src + (long)(q + gridDim.y) * part_stride);
+            const float4 c = *(const float4*)(src + (long)(q + 2 * gridDim.y) * part_stride);
+            const float4 d = *(const float4*)(src + (long)(q + 3 * gridDim.y) * part_stride);
+            v.x += (a.x + b.x) + (c.x + d.x); v.y += (a.y + b.y) + (c.y + d.y);
+            v.z += (a.z + b.z) + (c.z + d.z); v.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; q < parts; q += gridDim.y) {
+            const float4 a = *(const float4*)(src + (long)q * part_stride);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long s = m.src_index(k + e, tap, n);
+            if (s < 0) continue;
+            if (gridDim.y > 1) atomicAdd(dw + s, ve[e]);
+            else dw[s] = accumulate ? dw[s] + ve[e] : ve[e];
+        }
+    }
+}
+
+// 3x3 forward-layout gradients (mode 0, 9 taps): the destination OIHW order has the 9 taps of one (co, ci) adjacent, the
+// packed order has them k_pad apart.  A workgroup-iteration covers 1024 >> pl (row, k) pairs: its 256 threads are
+// (256 >> pl) positions of 4 consecutive k  x  (1 << pl) part lanes; every thread sums its share of the parts with 16-byte
+// loads, the 9216 partial values meet in LDS, are summed over the part lanes there, and leave as runs that are
+// contiguous in the destination (when the weight has no padding / permutation: `contig`) -- no atomics, no zero pass.
+__global__ __launch_bounds__(256) void unpack9_kernel(const float* __restrict__ dwp, int parts, long part_stride, float* __restrict__ dw, PackMap m,
+                                                      int k_pad, int accumulate, long total_nk, int contig, int pl) {
+    __shared__ float buf[1024 * 9];
+    const int tid = threadIdx.x;
+    const int PL = 1 << pl, ppb = 1024 >> pl;            // part lanes, pairs per workgroup-iteration
+    const int pos = tid & ((256 >> pl) - 1), plane = tid >> (8 - pl);
+    for (long base = (long)blockIdx.x * ppb; base < total_nk; base += (long)gridDim.x * ppb) {
+        const long i = base + pos * 4;
+        float4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total_nk) {
+            const long n = i / k_pad;
+            const int k = (int)(i - n * k_pad);
+            const float* src = dwp + n * 9 * k_pad + k;
+            for (int q = plane; q < parts; q += PL) {
+                const float* sq = src + (long)q * part_stride;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4 a = *(const float4*)(sq + (long)t * k_pad);
+                    v[t].x += a.x; v[t].y += a.y; v[t].z += a.z; v[t].w += a.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            buf[(tid * 4 + 0) * 9 + t] = v[t].x; buf[(tid * 4 + 1) * 9 + t] = v[t].y;
+            buf[(tid * 4 + 2) * 9 + t] = v[t].z; buf[(tid * 4 + 3) * 9 + t] = v[t].w;
+        }
+        __syncthreads();
+        const long left = total_nk - base;
+        const int np = (int)(left < ppb ? left : ppb) * 9;
+        for (int pp = tid; pp < np; pp += 256) {
+            float sum = 0.f;
+            for (int l = 0; l < PL; ++l) sum += buf[l * (ppb * 9) + pp];
+            long sidx;
+            if (contig) sidx = base * 9 + pp;
+            else {
+                const int j = pp / 9, t = pp - j * 9;
+                const long ii = base + j;
+                const long n = ii / k_pad;
+                sidx = m.src_index((int)(ii - n * k_pad), t, (int)n);
+                if (sidx < 0) continue;
+            }
+            dw[sidx] = accumulate ? dw[sidx] + sum : sum;
+        }
+        __syncthreads();
     }
 }
 
@@ -141,7 +212,8 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
     PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm, 0};
     const long total = (long)m.taps * k_pad * n_pad;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const long threads = total / (dtype == PSSR_F32 ? 4 : 8);
+    const int blocks = (int)((threads + 255) / 256 < 4096 ? (threads + 255) / 256 : 4096);
     if (dtype == PSSR_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, m, k_pad, n_pad, total);
     else if (dtype == PSSR_F16)
@@ -167,8 +239,19 @@ extern "C" int pssr_unpack_conv_wgrad_parts(const float* dwp, int parts, int row
     PSSR_CHECK(mode == 0 || mode == 2 || mode == 4, PSSR_ERR_ARG, "unpack: mode=%d", mode);
     PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm, 0};
     const long total = (long)cout * m.taps * k_pad;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int blocks = (int)((total / 4 + 255) / 256 < 4096 ? (total / 4 + 255) / 256 : 4096);
     // enough workgroups to pull the partial slabs at HBM rate: split the parts over blockIdx.y when the slab is small
+    if (mode == 0 && m.taps == 9) {
+        const long total_nk = (long)cout * k_pad;
+        int pl = 0;      // part lanes: as many as keep the grid within ~2048 workgroups (and no more than there are parts)
+        while (pl < 6 && (2 << pl) <= parts && (total_nk << (pl + 1)) / 1024 <= 2048) ++pl;
+        const long b9 = ((total_nk << pl) + 1023) / 1024;
+        const int contig = n_perm == nullptr && ci_begin == 0 && ci_count == cin && k_pad == cin;
+        hipLaunchKernelGGL(unpack9_kernel, dim3((unsigned)(b9 < 4096 ? b9 : 4096)), dim3(256), 0, (hipStream_t)stream, dwp, parts,
+                           (long)rows * m.taps * k_pad, dw, m, k_pad, accumulate, total_nk, contig, pl);
+        PSSR_LAUNCH_CHECK();
+        return PSSR_OK;
+    }
     int psplit = 2048 / blocks;
     if (psplit > parts / 4) psplit = parts / 4;
     if (psplit < 1) psplit = 1;
