@@ -48,46 +48,78 @@ struct PackMap {
     }
 };
 
-// one 16-byte slot (EPS consecutive K positions of one (chunk, tap, n)) per thread: a single 16-byte store
+// generic path: one packed element per thread
 template <typename T>
-__device__ __forceinline__ void pack_slots(const float* __restrict__ w, T* __restrict__ packed, const PackMap& m, int k_pad, int n_pad) {
+__device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __restrict__ packed, const PackMap& m, int k_pad, int n_pad) {
     constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
-    const long slots = (long)m.taps * k_pad * n_pad / EPS;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < slots; i += (long)gridDim.x * blockDim.x) {
-        long t = i;
+    const long total = (long)m.taps * k_pad * n_pad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = i % EPS;
+        long t = i / EPS;
         const int slotpos = t % 2; t /= 2;
         const int n = t % n_pad; t /= n_pad;
         const int tap = t % m.taps;
         const int chunk = t / m.taps;
         const int slot = slotpos ^ ((n >> 3) & 1);
-        const int k0 = chunk * KCH + slot * EPS;
-        float f[EPS];
-#pragma unroll
-        for (int e = 0; e < EPS; ++e) {
-            const long s = m.src_index(k0 + e, tap, n);
-            f[e] = s >= 0 ? w[s] : 0.f;
+        const int k = chunk * KCH + slot * EPS + e;
+        const long s = m.src_index(k, tap, n);
+        packed[i] = s >= 0 ? (T)w[s] : (T)0.f;
+    }
+}
+
+// 3x3 weights, forward (mode 0) or input-gradient (mode 1) layout: a workgroup-iteration builds the 9 tap slices of one
+// (K chunk, 128-wide N tile) in LDS from source runs that are contiguous in OIHW order (mode 0: 9*KCH floats per output
+// channel, mode 1: 9*128 floats per output channel) and stores each slice as 4 KB of contiguous 16-byte pieces.
+template <typename T>
+__device__ __forceinline__ void pack_tiles33(const float* __restrict__ w, T* __restrict__ packed, const PackMap& m, int k_pad, int n_pad, char* lds) {
+    constexpr int EPS = TT<T>::EPS, KCH = TT<T>::KCH;
+    const int tid = threadIdx.x;
+    const int n_tiles = n_pad / 128, tiles = (k_pad / KCH) * n_tiles;
+    const int gk = m.mode == 0 ? m.ci_count : m.cout, gn = m.mode == 0 ? m.cout : m.ci_count;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int c = tile / n_tiles, n0 = (tile % n_tiles) * 128;
+        for (int l = tid; l < 128 * KCH * 9; l += 256) {
+            int nl, kl, ts;
+            if (m.mode == 0) { nl = l / (KCH * 9); const int r = l - nl * (KCH * 9); kl = r / 9; ts = r - kl * 9; }
+            else { kl = l / (128 * 9); const int r = l - kl * (128 * 9); nl = r / 9; ts = r - nl * 9; }
+            const int k = c * KCH + kl, n = n0 + nl;
+            float v = 0.f;
+            if (k < gk && n < gn) {
+                const int o = m.mode == 0 ? n : k, ci = m.mode == 0 ? k : n;
+                const int co = m.n_perm ? m.n_perm[o] : o;
+                v = w[((long)co * m.cin + m.ci_begin + ci) * 9 + ts];
+            }
+            const int tap = m.mode == 0 ? ts : 8 - ts;
+            *(T*)(lds + (tap * 128 + nl) * 32 + (((kl / EPS) ^ ((n >> 3) & 1)) << 4) + (kl % EPS) * (int)sizeof(T)) = (T)v;
         }
-        *(u32x4*)(packed + i * EPS) = TT<T>::pack(f);
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            *(u32x4*)((char*)packed + (((long)c * 9 + tap) * n_pad + n0) * 32 + tid * 16) = *(const u32x4*)(lds + tap * 4096 + tid * 16);
+        __syncthreads();
     }
 }
 
 template <typename T>
-__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ packed, PackMap m, int k_pad, int n_pad, long total) {
-    pack_slots<T>(w, packed, m, k_pad, n_pad);
+__device__ __forceinline__ void pack_any(const float* __restrict__ w, T* __restrict__ packed, const PackMap& m, int k_pad, int n_pad, char* lds) {
+    if (m.ks == 3 && m.mode <= 1 && !m.center) pack_tiles33<T>(w, packed, m, k_pad, n_pad, lds);
+    else pack_elems<T>(w, packed, m, k_pad, n_pad);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, T* __restrict__ packed, PackMap m, int k_pad, int n_pad, long total) {
+    __shared__ __attribute__((aligned(16))) char lds[9 * 128 * 32];
+    pack_any<T>(w, packed, m, k_pad, n_pad, lds);
 }
 
 // every weight of a model in ONE launch: blockIdx.y selects the item (a training step re-packs ~100 weights)
-template <typename T>
-__device__ __forceinline__ void pack_item(const pssr_pack_item& it, const PackMap& m) {
-    pack_slots<T>(it.w, (T*)it.packed, m, it.k_pad, it.n_pad);
-}
-
-__global__ void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void pack_batch_kernel(const pssr_pack_item* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) char lds[9 * 128 * 32];
     const pssr_pack_item it = items[blockIdx.y];
     const PackMap m{it.cout, it.cin, it.ks, it.ci_begin, it.ci_count, it.mode, it.mode >= 2 ? 1 : it.ks * it.ks, it.n_perm, it.center};
-    if (it.dtype == PSSR_BF16) pack_item<bf16_t>(it, m);
-    else if (it.dtype == PSSR_F16) pack_item<f16_t>(it, m);
-    else pack_item<float>(it, m);
+    if (it.dtype == PSSR_BF16) pack_any<bf16_t>(it.w, (bf16_t*)it.packed, m, it.k_pad, it.n_pad, lds);
+    else if (it.dtype == PSSR_F16) pack_any<f16_t>(it.w, (f16_t*)it.packed, m, it.k_pad, it.n_pad, lds);
+    else pack_any<float>(it.w, (float*)it.packed, m, it.k_pad, it.n_pad, lds);
 }
 
 // dW packed layout produced by the wgrad kernel: f32 [parts][rows][tap][k_pad].  blockIdx.y owns a strided subset of the
@@ -212,8 +244,7 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
     PSSR_CHECK(k_pad >= gk && n_pad >= gn, PSSR_ERR_ARG, "pack: padding smaller than GEMM dims (%d<%d or %d<%d)", k_pad, gk, n_pad, gn);
     PackMap m{cout, cin, ks, ci_begin, ci_count, mode, mode >= 2 ? 1 : ks * ks, n_perm, 0};
     const long total = (long)m.taps * k_pad * n_pad;
-    const long threads = total / (dtype == PSSR_F32 ? 4 : 8);
-    const int blocks = (int)((threads + 255) / 256 < 4096 ? (threads + 255) / 256 : 4096);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == PSSR_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, m, k_pad, n_pad, total);
     else if (dtype == PSSR_F16)
@@ -228,7 +259,7 @@ extern "C" int pssr_pack_conv_weight(const float* w, void* packed, int cout, int
 
 extern "C" int pssr_pack_conv_weight_batch(const pssr_pack_item* items_dev, int n_items, pssr_stream_t stream) {
     PSSR_CHECK(items_dev && n_items > 0 && n_items <= 65535, PSSR_ERR_ARG, "pack_batch: bad args");
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(96, n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(384, n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
