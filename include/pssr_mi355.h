@@ -374,6 +374,13 @@ int pssr_head_conv_dgrad(const float* g_nchw, float g_scale, const float* w_oihw
                          pssr_stream_t stream);
 int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, int act_cs, int act_co, int blk,
                          float* dw_oihw, int n, int h, int w, int cin, int cout, int dtype, pssr_stream_t stream);
+/* dgrad and wgrad in ONE pass over the activation (each tile is read once and used as ReLU mask, as the dW operand and for
+ * the optional bias sums): dact and dw_oihw as above (blk <= 2); bias_sum (or NULL) is a caller-zeroed f32
+ * [4^blk * cin] that receives sum_pixels dact per (sub-pixel, channel) = per channel of the blocked NHWC tensor viewed at
+ * low resolution, i.e. the bias gradient of the pixel-shuffle convolution in front (Reconstruction.pre). */
+int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co,
+                       void* dact, int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin,
+                       int cout, int dtype, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-sheet prediction on the device (BASELINE config 5).

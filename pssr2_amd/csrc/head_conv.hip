@@ -279,6 +279,197 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadArgs p, int n
         }
 }
 
+// ------------------------------------------------------------------------------------------------ dgrad + wgrad in one pass
+// The two backward kernels above each stream the 1 GB activation tensor; this one reads every activation tile once and
+// uses it three times from LDS: as the ReLU mask of dP, as the MFMA operand of dW (transposing LDS reads, as in
+// conv_wgrad.hip) and -- optionally -- to keep per-channel sums of dP (the bias gradient of the preceding pixel-shuffle
+// convolution, whose channels are (sub-pixel, ci) in the blocked order).  Workgroups are persistent over tiles: the
+// activation pieces of the next tile are in flight while this one is multiplied; dW stays in accumulators.
+template <typename H> struct HV32;
+template <> struct HV32<bf16_t> {
+    static __device__ __forceinline__ f32x16 mma(const u32x4& a, const u32x4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct HV32<f16_t> {
+    static __device__ __forceinline__ f32x16 mma(const u32x4& a, const u32x4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ u32x4 tr_frag(const char* a0, const char* a1) {      // two ds_read_b64_tr_b16 (see conv_wgrad.hip)
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1));
+    u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
+}
+
+template <typename H, int NT, bool BS>     // NT = cin/16; cout*9 <= 27; BS: keep the bias sums (NT = 2, 4 or 8)
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs p, int n_tiles, float* bsum) {
+    typedef typename HV<H>::v8 v8;
+    constexpr int C = NT * 16, CI_S = NT / 2, PPP = C / 8;          // channels, 32-channel sub-tiles, 16-byte pieces per pixel
+    constexpr int G_BYTES = ((3 * HPIX * 4 + 15) / 16) * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* G = (float*)smem;                                        // [cout][HS][HS] incoming gradient tile (+halo), scaled
+    char* Pt = smem + G_BYTES;                                      // [CI_S][256 px][64 B] activation tile
+    H* O = (H*)(Pt + 256 * C * 2);                                  // [256 px][C] dP before the mask
+    float* Bs = (float*)((char*)O + 256 * C * 2);                   // [16 sub-pixels][C] bias sums of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bshift = p.blk, bmask = (1 << p.blk) - 1;
+
+    v8 bw[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = wfrag_bwd<H>(p, nt, lane);
+    f32x16 accw[CI_S];
+#pragma unroll
+    for (int s_ = 0; s_ < CI_S; ++s_)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[s_][e] = 0.f;
+    // wgrad A operand: row m = (co, tap) of this lane, offset of its g value for tile pixel (0, 0)
+    const int wm_ = lane & 31, wh_ = lane >> 5;
+    const int w_co = wm_ / 9, w_tap = wm_ % 9;
+    const int gbase = (w_co < p.cout) ? w_co * HPIX + (2 - w_tap / 3) * HS + (2 - w_tap % 3) + 8 * wh_ : -1;
+    // wgrad B operand (transposing read): lane 4q+pc of each 16-lane group addresses row q, columns 4pc..4pc+3
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tpc = lane & 3;
+    const int tr_off = ((tg >> 1) * 8 + tq) * 64 + ((tg & 1) * 16 + tpc * 4) * 2;
+    for (int i = tid; i < 16 * C; i += 256) Bs[i] = 0.f;
+    // dgrad A operand: k = (co, tap) slots 8 * (lane >> 4) + j of this lane, as offsets into G for tile pixel (0, 0)
+    int doff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = 8 * (lane >> 4) + j;
+        const int co = m / 9, tap = m % 9;
+        doff[j] = co < p.cout ? co * HPIX + (2 - tap / 3) * HS + 2 - tap % 3 : -1;
+    }
+    // bias sums: piece u of a thread is pixel tid / PPP + u * PXU of the tile, i.e. (for PXU a multiple of the tile width)
+    // always the same column and a row that moves by PXU / TS per u: NS distinct sub-pixel rows
+    constexpr int PXU = 256 / PPP, NS = BS ? (PXU >= 4 * TS ? 1 : 4 * TS / PXU) : 1;
+    static_assert(!BS || (256 % PPP == 0 && PXU % TS == 0), "bias sums need a power-of-two piece count");
+    float bacc[NS][8];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bacc[k][j] = 0.f;
+
+    u32x4 pre[PPP];
+    long qv[PPP];
+#define HB_ISSUE(TILE)                                                                                                  \
+    {                                                                                                                   \
+        int t_ = (TILE);                                                                                                \
+        const int tx0_ = (t_ % p.tiles_x) * TS; t_ /= p.tiles_x;                                                        \
+        const int ty0_ = (t_ % p.tiles_y) * TS;                                                                         \
+        const int img_ = t_ / p.tiles_y;                                                                                \
+        _Pragma("unroll") for (int u = 0; u < PPP; ++u) {                                                               \
+            const int i = tid + u * 256;                                                                                \
+            const int pix = i / PPP, pc = i % PPP;                                                                      \
+            const int gy = ty0_ + pix / TS, gx = tx0_ + pix % TS;                                                       \
+            const bool ok = gy < p.H && gx < p.W;                                                                       \
+            qv[u] = ok ? pix_index(img_, gy, gx, p.H, p.W, p.blk) : -1;                                                 \
+            pre[u] = *(const u32x4*)((const H*)p.P + (ok ? qv[u] : pix_index(img_, ty0_, tx0_, p.H, p.W, p.blk)) * p.p_cs + p.p_co + pc * 8); \
+        }                                                                                                               \
+    }
+    int tile = blockIdx.x;
+    if (tile < n_tiles) HB_ISSUE(tile)
+    for (; tile < n_tiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx0 = (t % p.tiles_x) * TS; t /= p.tiles_x;
+        const int ty0 = (t % p.tiles_y) * TS;
+        const int img = t / p.tiles_y;
+        // ---- stage: activation pieces (prefetched) and the gradient tile
+        long qcur[PPP];
+#pragma unroll
+        for (int u = 0; u < PPP; ++u) {
+            const int i = tid + u * 256;
+            const int pix = i / PPP, pc = i % PPP;
+            qcur[u] = qv[u];
+            u32x4 v = pre[u];
+            if (qv[u] < 0) v = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4*)(Pt + (pc / 4) * (256 * 64) + pix * 64 + (pc % 4) * 16) = v;
+        }
+        for (int i = tid; i < p.cout * HPIX; i += 256) {
+            const int co = i / HPIX, hp = i % HPIX;
+            const int gy = ty0 + hp / HS - 1, gx = tx0 + hp % HS - 1;
+            G[i] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? p.g[(((long)img * p.cout + co) * p.H + gy) * p.W + gx] * p.g_scale : 0.f;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) HB_ISSUE(tile + gridDim.x)
+
+        // ---- dP = g (*) W, 16 pixels (one tile row) per MFMA chain
+        for (int g = wave; g < 16; g += 4) {
+            const int px = lane & 15, py = g;
+            v8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (H)(doff[j] >= 0 ? G[doff[j] + py * HS + px] : 0.f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4_t acc = HV<H>::mma(a, bw[nt], f32x4_t{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) O[(g * 16 + (lane >> 4) * 4 + r) * C + nt * 16 + (lane & 15)] = (H)acc[r];
+            }
+        }
+        // ---- dW[(co,tap)][ci] += sum over the tile's pixels of g[q - off(tap)] * P[q]: k-steps of 16 pixels = tile rows
+        for (int ks = wave; ks < 16; ks += 4) {
+            float gv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = gbase >= 0 ? G[gbase + ks * HS + j] : 0.f;
+            u32x4 af;
+            {
+                v8 a8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (H)gv[j];
+                af = __builtin_bit_cast(u32x4, a8);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < CI_S; ++s_) {
+                const char* b0 = Pt + s_ * (256 * 64) + ks * 16 * 64 + tr_off;
+                accw[s_] = HV32<H>::mma(af, tr_frag(b0, b0 + 4 * 64), accw[s_]);
+            }
+        }
+        __syncthreads();
+        // ---- masked write-out (16-byte pieces, whole pixel rows per wave) + bias sums per (sub-pixel, channel)
+#pragma unroll
+        for (int u = 0; u < PPP; ++u) {
+            if (qcur[u] < 0) continue;
+            const int i = tid + u * 256;
+            const int pix = i / PPP, pc = i % PPP;
+            v8 v = *(const v8*)(O + pix * C + pc * 8);
+            const v8 actv = *(const v8*)(Pt + (pc / 4) * (256 * 64) + pix * 64 + (pc % 4) * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!((float)actv[j] > 0.f)) v[j] = (H)0.f;
+            *(v8*)((H*)p.dP + qcur[u] * p.dp_cs + p.dp_co + pc * 8) = v;
+            if (BS) {       // this thread's piece u always lies on sub-pixel row set u % NS and one sub-pixel column
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bacc[u % NS][j] += (float)v[j];
+            }
+        }
+        __syncthreads();
+    }
+#undef HB_ISSUE
+    // ---- dW: one f32 atomic per weight and wave
+    const int kcol = lane & 31;
+#pragma unroll
+    for (int s_ = 0; s_ < CI_S; ++s_)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (m < p.cout * 9) atomicAdd(p.dw + ((long)(m / 9) * p.cin + s_ * 32 + kcol) * 9 + m % 9, accw[s_][e]);
+        }
+    if (BS) {
+        const int pix0 = tid / PPP, pc = tid % PPP;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int sub = (((pix0 / TS + k * (PXU / TS)) & bmask) << bshift) + ((pix0 % TS) & bmask);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(Bs + sub * C + pc * 8 + j, bacc[k][j]);
+        }
+        __syncthreads();
+        const int nsub = 1 << (2 * p.blk);
+        for (int i = tid; i < nsub * C; i += 256) atomicAdd(bsum + i, Bs[i]);
+    }
+}
+
 int check_common(const void* P, int cs, int co, int blk, int n, int h, int w, int cin, int cout, int dtype, const char* what) {
     PSSR_CHECK(dtype == PSSR_BF16 || dtype == PSSR_F16, PSSR_ERR_UNSUPPORTED, "%s: 16-bit storage only (use pssr_conv2d for the exact-f32 build)", what);
     PSSR_CHECK(P && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "%s: bad shape", what);
@@ -360,6 +551,39 @@ int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, in
     if (dtype == PSSR_BF16) { if (cout == 1) HW(bf16_t, 1); else if (cout == 2) HW(bf16_t, 2); else HW(bf16_t, 3); }
     else { if (cout == 1) HW(f16_t, 1); else if (cout == 2) HW(f16_t, 2); else HW(f16_t, 3); }
 #undef HW
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
+                       int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin, int cout, int dtype,
+                       pssr_stream_t s) {
+    int rc = check_common(act, act_cs, act_co, blk, n, h, w, cin, cout, dtype, "head_conv_bwd");
+    if (rc != PSSR_OK) return rc;
+    PSSR_CHECK(g_nchw && w_oihw && dact && dw_oihw && d_cs % 8 == 0 && d_co % 8 == 0 && d_co + cin <= d_cs, PSSR_ERR_ARG, "head_conv_bwd: bad args");
+    PSSR_CHECK(blk <= 2, PSSR_ERR_ARG, "head_conv_bwd: blocked order up to 4x4 sub-pixels");
+    HeadArgs a{};
+    a.P = act; a.p_cs = act_cs; a.p_co = act_co; a.blk = blk; a.dP = dact; a.dp_cs = d_cs; a.dp_co = d_co;
+    a.w = w_oihw; a.g = g_nchw; a.g_scale = g_scale; a.dw = dw_oihw;
+    a.N = n; a.H = h; a.W = w; a.cin = cin; a.cout = cout; a.tiles_x = cdiv(w, TS); a.tiles_y = cdiv(h, TS);
+    const long tiles = (long)a.tiles_x * a.tiles_y * n;
+    PSSR_CHECK(tiles < (1L << 31), PSSR_ERR_ARG, "head_conv_bwd: grid");
+    const int lds = ((3 * HPIX * 4 + 15) / 16) * 16 + 2 * 256 * cin * 2 + 16 * cin * 4;
+    const int grid = tiles < 512 ? (int)tiles : 512;
+#define HB(NT_, BS_)                                                                                                       \
+    do {                                                                                                                \
+        if (dtype == PSSR_BF16) {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<bf16_t, NT_, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((head_bwd_kernel<bf16_t, NT_, BS_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum); \
+        } else {                                                                                                        \
+            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<f16_t, NT_, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((head_bwd_kernel<f16_t, NT_, BS_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum); \
+        }                                                                                                               \
+    } while (0)
+    PSSR_CHECK(!bias_sum || cin == 32 || cin == 64 || cin == 128, PSSR_ERR_ARG, "head_conv_bwd: bias sums need cin = 32, 64 or 128");
+    if (bias_sum) { switch (cin / 16) { case 2: HB(2, true); break; case 4: HB(4, true); break; default: HB(8, true); break; } }
+    else { switch (cin / 16) { case 2: HB(2, false); break; case 4: HB(4, false); break; case 6: HB(6, false); break; default: HB(8, false); break; } }
+#undef HB
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -451,9 +451,15 @@ class Engine:
             ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * 2 * self.cout], gb)
             grads[id(rec.conv.bias)] = gb[:self.cout]
             gw = grads[id(rec.conv.weight)] = self._gbuf(rec.conv.weight)
-            ops.head_conv_wgrad(dout, 128.0, pre_hr, self.blk, gw, n, H, W, h0, self.cout, code)
-            ops.head_conv_dgrad(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, n, H, W, h0, self.cout, code)
+            # dgrad + wgrad + the bias sums of Reconstruction.pre in one pass over the HR activation
+            gpb = torch.zeros(r * r * h0, dtype=torch.float32, device=dev) if (self.blk <= 2 and h0 in (32, 64, 128)) else None
+            if gpb is not None:
+                ops.head_conv_bwd(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, gw, gpb, n, H, W, h0, self.cout, code)
+            else:
+                ops.head_conv_wgrad(dout, 128.0, pre_hr, self.blk, gw, n, H, W, h0, self.cout, code)
+                ops.head_conv_dgrad(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, n, H, W, h0, self.cout, code)
         else:
+            gpb = None
             ops.nchw_to_nhwc(dout, bw.g_hr, 128.0, code)
             bw.sum64.zero_()
             ops.channel_sum_nhwc(bw.g_hr, n * H * W, 16, bw.sum64, code)
@@ -466,10 +472,11 @@ class Engine:
                        aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
         # ---- Reconstruction.pre (two sources)
         cpre_n = r * r * h0
-        bw.sum64.zero_()
-        ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
-        gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
-        ops.f64_to_f32(bw.sum64, gpb)
+        if gpb is None:
+            bw.sum64.zero_()
+            ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
+            gpb = torch.empty(cpre_n, dtype=torch.float32, device=dev)
+            ops.f64_to_f32(bw.sum64, gpb)
         gb_pre = torch.empty_like(gpb)
         gb_pre[self.pre_perm_long] = gpb
         grads[id(rec.pre.bias)] = gb_pre

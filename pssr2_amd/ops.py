@@ -425,3 +425,9 @@ def patch_tiles_u8(tiles, n_rows, n_cols, overlap, margin):
     out = torch.empty(c, n_rows * step + overlap, n_cols * step + overlap, dtype=torch.uint8, device=tiles.device)
     L.check(L.lib().pssr_patch_tiles_u8(L.ptr(tiles), L.ptr(out), c, n_rows, n_cols, size, overlap, margin, L.stream_ptr()), "pssr_patch_tiles_u8")
     return out
+
+
+def head_conv_bwd(g, g_scale, weight, act, dact, blk, dw, bias_sum, n, h, w, cin, cout, dtype):
+    """dgrad + wgrad (+ the bias sums of the pixel-shuffle conv in front) in one pass over the activation."""
+    L.check(L.lib().pssr_head_conv_bwd(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
+                                       blk, L.ptr(dw), L.ptr(bias_sum), n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_bwd")

@@ -51,3 +51,15 @@ def test_head_conv(case, dt):
     dw = base.clone().cuda()
     ops.head_conv_wgrad(dout.cuda(), 128.0, ad, blk, dw, n, h, w, cin, cout, code)
     np.testing.assert_allclose((dw.cpu() - base).numpy(), wq.grad.numpy(), rtol=1e-3, atol=1e-3 * wq.grad.abs().max().item())
+    # dgrad + wgrad + bias sums in one pass (the path the engine takes): same dact, dW from bf16/fp16 MFMA operands
+    if blk <= 2:
+        da2 = torch.full_like(ad, 7.0)
+        dw2 = base.clone().cuda()
+        r = 1 << blk
+        bsum = torch.zeros(r * r * cin, device="cuda") if cin in (32, 64, 128) else None
+        ops.head_conv_bwd(dout.cuda(), 128.0, wt.cuda().contiguous(), ad, da2, blk, dw2, bsum, n, h, w, cin, cout, code)
+        assert torch.equal(da2, da)
+        np.testing.assert_allclose((dw2.cpu() - base).numpy(), wq.grad.numpy(), rtol=2e-2, atol=1e-2 * wq.grad.abs().max().item())
+        if bsum is not None:
+            want_b = da.float().cpu().reshape(n, h // r, w // r, r * r * cin).sum(dim=(0, 1, 2))
+            np.testing.assert_allclose(bsum.cpu().numpy(), want_b.numpy(), rtol=1e-3, atol=1e-3 * want_b.abs().max().item())
