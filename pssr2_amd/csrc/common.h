@@ -165,6 +165,26 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
     return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
 }
 
+// 16-bit storage builds: Phi(z) from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 / fp16 resolution), which
+// shares its exp(-z^2/2) with the density term of the derivative: ~15 instructions instead of erff + expf (the GELU
+// epilogue of a 64 -> 1024 1x1 dgrad was VALU-bound on them).  The exact-f32 build keeps erff.
+__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& ez) {
+    const float u = fabsf(z) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.f));
+    ez = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170f);         // exp(-z^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float tail = 0.5f * poly * ez;                                 // 1 - Phi(|z|)
+    cdf = z >= 0.f ? 1.f - tail : tail;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float z) {
+    if constexpr (sizeof(T) == 4) return gelu_f(z);
+    else { float cdf, ez; gelu_parts(z, cdf, ez); return z * cdf; }
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float z) {
+    if constexpr (sizeof(T) == 4) return gelu_grad_f(z);
+    else { float cdf, ez; gelu_parts(z, cdf, ez); return fmaf(z * 0.39894228040143268f, ez, cdf); }
+}
+
 // Pixel linearisation: plain NHWC, or "blocked" order of an r-times (r = 1<<blk) upsampled image
 // (see pssr_conv_desc in include/pssr_mi355.h).
 __device__ __forceinline__ long pix_index(int gi, int gy, int gx, int H, int W, int blk) {

@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
                 } else if (p.epi == PSSR_EPI_DGRAD_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(a[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -250,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
             for (int e = 0; e < 8; ++e) {
                 if (EPI == PSSR_EPI_STORE) v[e] = fmaxf(v[e] + bias[e], relu_lo);
                 else if (EPI == PSSR_EPI_TAIL) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
-                else if (EPI == PSSR_EPI_DGRAD_GELU) v[e] *= gelu_grad_f(a[e]);
+                else if (EPI == PSSR_EPI_DGRAD_GELU) v[e] *= gelu_grad_t<T>(a[e]);
                 else {
                     v[e] = (fmaf(a[e], xs[e], xh[e]) > 0.f) ? v[e] : 0.f;
                     a[e] = (a[e] - xm[e]) * xi[e];       // xhat
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                      \
                         float f[EPS];                                                                             \
                         X::unpack(v, f);                                                                          \
-                        _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                      \
+                        _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                      \
                         v = X::pack(f);                                                                           \
                     }                                                                                             \
                     *(u32x4*)(As + a_lds[it]) = v;                                                                \
@@ -561,6 +561,150 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
                     const float4 v = src[((mi * C::NJ + nj) * 4 + q) * 256];
                     acc[mi][nj][4 * q] += v.x; acc[mi][nj][4 * q + 1] += v.y; acc[mi][nj][4 * q + 2] += v.z; acc[mi][nj][4 * q + 3] += v.w;
                 }
+    }
+    conv_epilogue_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
+}
+
+// =================================================================================================================
+// 1x1 convolutions (single source, no BatchNorm prologue).  With one tap the loop above multiplies only 4 MFMAs per wave
+// between two barriers and a full staging round (measured 50-110 TFLOP/s on RDNet's 1x1 layers).  Here a stage is KC
+// consecutive 32-byte channel chunks: a thread stages the same (pixel, 16-byte half) for all KC chunks (constant offsets
+// from one address), the weight slices of KC chunks are one contiguous run of the 1-tap packed layout, and a wave
+// multiplies 4 * KC MFMAs per stage -- the 9-tap loop's density without a halo.
+template <typename T, int BN, int GEO, int KC>
+__global__ __launch_bounds__(256) void conv_flat_kernel(const ConvArgs p) {
+    using C = Cfg<BN, GEO>;
+    using X = TT<T>;
+    constexpr int EPS = X::EPS;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int A_BYTES = KC * 128 * 32;
+    constexpr int PT = BN * 2, TPI = 256 / PT, NB = (KC * PT + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                        // [KC][128 px][32 B]
+    char* Bs = smem + A_BYTES;              // [KC][BN][32 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int h = lane >> 5, r = lane & 31;
+    const int bid = blockIdx.x;
+    const int tn = bid % p.tiles_n;
+    int tmi = bid / p.tiles_n;
+    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
+    const int tile_y = tmi % p.tiles_y;
+    const int tile_i = tmi / p.tiles_y;
+    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, img0 = tile_i * C::NI, n0 = tn * BN;
+
+    // staging: thread <-> (pixel tid >> 1, half tid & 1), item <-> chunk of the stage
+    const long img_base = (long)img0 * p.H * p.W;
+    const int pm = tid >> 1, half = tid & 1;
+    bool a_ok;
+    unsigned a_off;
+    {
+        const int tx = pm & (C::TW - 1), ty = (pm >> C::TWL) & (C::TH - 1), img = pm >> (C::TWL + C::THL);
+        const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
+        a_ok = gi < p.N && gy < p.H && gx < p.W;
+        a_off = a_ok ? (unsigned)((pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) - img_base) * p.in_cs[0] * ESZ + half * 16) : 0u;
+    }
+    const int a_lds = pm * 32 + ((half ^ ((pm >> 3) & 1)) << 4);
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.in[0] + (img_base * p.in_cs[0] + p.in_co[0]) * ESZ), 0, (int)0xfffffff0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w[0] + (long)n0 * 32), 0, (int)0xfffffff0u, 0x00020000);
+    const int tap_stride = p.n_pad * 32;                            // one chunk of the 1-tap packed weights
+    const unsigned b_voff = (unsigned)((tid / PT) * tap_stride + (tid % PT) * 16);
+    const unsigned b_voff_tail = (unsigned)((tid % PT) * 16);
+    int a_rd[C::MI];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi) {
+        const int m = wm * C::MI * 32 + mi * 32 + r;
+        a_rd[mi] = m * 32 + ((h ^ ((m >> 3) & 1)) << 4);
+    }
+    int b_off[C::NJ];
+#pragma unroll
+    for (int nj = 0; nj < C::NJ; ++nj) {
+        const int n = wn * C::NJ * 32 + nj * 32 + r;
+        b_off[nj] = n * 32 + ((h ^ ((n >> 3) & 1)) << 4);
+    }
+    f32x16 acc[C::MI][C::NJ];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+    u32x4 a_reg[KC];
+    u32x4 b_reg[NB];
+    const int nch = p.nchunks[0];
+#define PF_ISSUE(U)                                                                                               \
+    {                                                                                                             \
+        const int rem_ = nch - (U) * KC;          /* chunks left: the last stage may be short */                  \
+        const int asoff_ = (U) * KC * 32, wsoff_ = (U) * KC * tap_stride;                                         \
+        _Pragma("unroll") for (int it = 0; it < KC; ++it) {                                                       \
+            if (it < rem_) a_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra0, (int)a_off, asoff_ + it * 32, 0)); \
+            else a_reg[it] = u32x4{0u, 0u, 0u, 0u};                                                               \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < NB; ++it) {                                                       \
+            const bool full_ = (it + 1) * 256 <= KC * PT;                                                         \
+            unsigned vo_ = full_ ? b_voff : b_voff_tail;                                                          \
+            if (rem_ < KC && it * TPI + (full_ ? tid / PT : 0) >= rem_) vo_ = 0xffffffffu;   /* zero-fill */      \
+            b_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw0, (int)vo_, wsoff_ + it * TPI * tap_stride, 0)); \
+        }                                                                                                         \
+    }
+#define PF_COMMIT()                                                                                               \
+    {                                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < KC; ++it) {                                                       \
+            u32x4 v = a_reg[it];                                                                                  \
+            if (!a_ok) v = u32x4{0u, 0u, 0u, 0u};                                                                 \
+            if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                            \
+                float f[EPS];                                                                                     \
+                X::unpack(v, f);                                                                                  \
+                _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                              \
+                v = X::pack(f);                                                                                   \
+            }                                                                                                     \
+            *(u32x4*)(As + it * 4096 + a_lds) = v;                                                                \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < NB; ++it) {                                                       \
+            const bool full_ = (it + 1) * 256 <= KC * PT;                                                         \
+            if (full_ || tid < KC * PT - it * 256) *(u32x4*)(Bs + tid * 16 + it * 4096) = b_reg[it];              \
+        }                                                                                                         \
+    }
+    int cb = 0, n0c = (nch + KC - 1) / KC;        // stages; split-K: blockIdx.y owns a range of them
+    if (p.ksplit > 1) {
+        const int per = (n0c + p.ksplit - 1) / p.ksplit;
+        cb = blockIdx.y * per;
+        n0c = cb + per < n0c ? cb + per : n0c;
+    }
+    if (cb < n0c) PF_ISSUE(cb)
+    for (int u = cb; u < n0c; ++u) {
+        PF_COMMIT()
+        __syncthreads();
+        if (u + 1 < n0c) PF_ISSUE(u + 1)
+#pragma unroll
+        for (int t = 0; t < KC; ++t) {
+            u32x4 af[C::MI], bf[C::NJ];
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi) af[mi] = *(const u32x4*)(As + t * 4096 + a_rd[mi]);
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]);
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);
+        }
+        __syncthreads();
+    }
+#undef PF_ISSUE
+#undef PF_COMMIT
+    if (p.ksplit > 1) {
+        float4* dst = (float4*)p.ws + ((long)blockIdx.x * p.ksplit + blockIdx.y) * (4 * C::MI * C::NJ) * 256 + tid;
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[((mi * C::NJ + nj) * 4 + q) * 256] = make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
+        return;
     }
     conv_epilogue_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
 }
@@ -703,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm2_kernel(const ConvArgs p) {
                 if (gelu_) {                                                                                      \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)((DST) + a_lds[it]) = v;                                                                 \
@@ -903,8 +1047,51 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     return PSSR_OK;
 }
 
+using pssr_conv::g_flat_mode;     // 1 (default): 1x1 convolutions take conv_flat_kernel (PSSR_IGEMM_FLAT=0 disables)
+
+template <typename T, int BN, int GEO, int KC>
+int launch_flat(const ConvArgs& a, hipStream_t stream) {
+    using C = Cfg<BN, GEO>;
+    constexpr int MAIN = KC * 128 * 32 + KC * BN * 32;
+    constexpr int LDS = MAIN > C::E_BYTES + C::RED_BYTES ? MAIN : C::E_BYTES + C::RED_BYTES;
+    ConvArgs p = a;
+    p.tiles_x = cdiv(a.W, C::TW);
+    p.tiles_y = cdiv(a.H, C::TH);
+    p.tiles_n = cdiv(a.cout, BN);
+    const long blocks = (long)p.tiles_x * p.tiles_y * cdiv(a.N, C::NI) * p.tiles_n;
+    PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
+    const int stages = cdiv(a.nchunks[0], KC);
+    int ksplit = 1;      // same policy as the 9-tap loop, in stages (a stage ~ a 9-tap chunk)
+    if (BN >= 64 && a.epi != PSSR_EPI_FINAL && blocks < 192 && stages >= 4) {
+        ksplit = (int)((384 + blocks - 1) / blocks);
+        if (ksplit > stages / 2) ksplit = stages / 2;
+        if (ksplit > 8) ksplit = 8;
+    }
+    const long ws_bytes = ksplit > 1 ? blocks * ksplit * (long)(64 * C::MI * C::NJ) * 256 : 0;
+    if (a.ksplit < 0) { *(long*)a.ws = ws_bytes; return PSSR_OK; }
+    if (ksplit > 1 && (a.ws == nullptr || (long)a.ksplit * 1024 < ws_bytes)) ksplit = 1;
+    p.ksplit = ksplit;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_flat_kernel<T, BN, GEO, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)conv_splitk_finish_kernel<T, BN, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_flat_kernel<T, BN, GEO, KC>), dim3((unsigned)blocks, ksplit), dim3(256), LDS, stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL((conv_splitk_finish_kernel<T, BN, GEO>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
 template <typename T, int BN, int GEO>
 int launch(const ConvArgs& a, hipStream_t s) {
+    if (a.taps[0] == 1 && a.nchunks[1] == 0 && a.prologue != PSSR_PRO_BN_RELU && g_flat_mode) {
+        // stage length: 9 chunks unless 4 wastes clearly less of the last stage (K = 64: 4 chunks)
+        const int n = a.nchunks[0];
+        const bool nine = n > 8 && cdiv(n, 9) * 9 * 100 <= cdiv(n, 4) * 4 * 115;
+        return nine ? launch_flat<T, BN, GEO, 9>(a, s) : launch_flat<T, BN, GEO, 4>(a, s);
+    }
     return a.taps[0] == 9 ? launch_t<T, BN, GEO, 9>(a, s) : launch_t<T, BN, GEO, 1>(a, s);
 }
 

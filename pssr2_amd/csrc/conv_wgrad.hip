@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && GEO < 2) ? 2 : 1) void conv
                 } else if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                 \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;                                       \
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
                 } else if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                 \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_f(f[e]);                          \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(Ah + ah_lds + it * (256 / AH_PPP) * ROWB) = v;                                          \

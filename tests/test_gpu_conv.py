@@ -48,6 +48,10 @@ CASES += [
     (2, 256, 128, 16, 16, 3),    # few tiles, long K: split-K (4 slices) + finish kernel
     (3, 640, 64, 8, 8, 1),       # 1x1 split-K, BN = 64, GEO 1
     (1, 144, 200, 12, 12, 3),    # split-K with an uneven chunk split and partial tiles
+    (2, 144, 96, 20, 20, 1),     # 1x1 stage-of-chunks loop: exactly one 9-chunk stage (bf16), partial tiles
+    (1, 1040, 64, 16, 16, 1),    # 1x1, 65 chunks: 9-chunk stages with a 2-chunk tail (zero-filled slices), BN = 64
+    (2, 208, 40, 8, 8, 1),       # 1x1, 13 chunks: 4-chunk stages with a 1-chunk tail, GEO 1, BN = 64 with cout % 32 != 0
+    (1, 2048, 256, 8, 8, 1),     # 1x1 split-K over stages
 ]
 
 
