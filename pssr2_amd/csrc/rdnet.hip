@@ -186,12 +186,14 @@ __global__ __launch_bounds__(256) void dwconv7_seg_kernel(Ref in, const float* _
                 else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
             }
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
+            for (int kx = 0; kx < 7; ++kx) {      // packed f32 FMAs (v_pk_fma_f32): the kernel is bound by the vector ALU
                 const float4 wv = *(const float4*)(wp + (ky * 7 + kx) * c + c0);
+                const f32x2 w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
-                    acc[o][0] = fmaf(v[o + kx][0], wv.x, acc[o][0]); acc[o][1] = fmaf(v[o + kx][1], wv.y, acc[o][1]);
-                    acc[o][2] = fmaf(v[o + kx][2], wv.z, acc[o][2]); acc[o][3] = fmaf(v[o + kx][3], wv.w, acc[o][3]);
+                    const f32x2 a01 = __builtin_elementwise_fma(f32x2{v[o + kx][0], v[o + kx][1]}, w01, f32x2{acc[o][0], acc[o][1]});
+                    const f32x2 a23 = __builtin_elementwise_fma(f32x2{v[o + kx][2], v[o + kx][3]}, w23, f32x2{acc[o][2], acc[o][3]});
+                    acc[o][0] = a01[0]; acc[o][1] = a01[1]; acc[o][2] = a23[0]; acc[o][3] = a23[1];
                 }
             }
         }
@@ -271,6 +273,53 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_seg_kernel(Ref dy, Ref x, f
         }
         __syncthreads();
     }
+}
+
+// Same sums with the 7 kernel rows spread over the THREADS of a workgroup instead of blockIdx.y: a thread is (kernel row ky,
+// channel group) and the workgroup walks consecutive output rows of one 8-pixel column, so the dy segment is fetched once
+// per workgroup (the 7 ky threads hit the same lines) and an input row serves the 7 kernel rows on consecutive iterations
+// from L1/L2 -- the blockIdx.y version above streams both tensors 7 times from HBM.
+template <typename T>
+__global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, float* __restrict__ dw, int n, int h, int w, int c, long per_block) {
+    const int cgc = c / 4, ws = w / 8;
+    const int ky = threadIdx.x / 32, cg = blockIdx.y * 32 + threadIdx.x % 32;
+    if (cg >= cgc) return;
+    const long nseg = (long)n * ws * h;                        // segment index = (img * ws + xseg) * h + y: y fastest
+    const long s0 = (long)blockIdx.x * per_block, s1 = s0 + per_block < nseg ? s0 + per_block : nseg;
+    float acc[7][4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+    for (long sgi = s0; sgi < s1; ++sgi) {
+        const int y = (int)(sgi % h);
+        const long t = sgi / h;
+        const int xs = (int)(t % ws) * 8;
+        const long img_base = (t / ws) * h * w;
+        const int sy = y + ky - 3;
+        if (sy < 0 || sy >= h) continue;
+        float g[8][4], v[14][4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) load4(at<T>(dy, img_base + (long)y * w + xs + o, cg * 4), g[o]);
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int sx = xs - 3 + j;
+            if (sx >= 0 && sx < w) load4(at<T>(x, img_base + (long)sy * w + sx, cg * 4), v[j]);
+            else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)       // packed f32 FMAs (v_pk_fma_f32): the kernel is bound by the vector ALU
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const f32x2 a01 = __builtin_elementwise_fma(f32x2{g[o][0], g[o][1]}, f32x2{v[o + kx][0], v[o + kx][1]}, f32x2{acc[kx][0], acc[kx][1]});
+                const f32x2 a23 = __builtin_elementwise_fma(f32x2{g[o][2], g[o][3]}, f32x2{v[o + kx][2], v[o + kx][3]}, f32x2{acc[kx][2], acc[kx][3]});
+                acc[kx][0] = a01[0]; acc[kx][1] = a01[1]; acc[kx][2] = a23[0]; acc[kx][3] = a23[1];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dw + (long)(cg * 4 + e) * 49 + ky * 7 + k, acc[k][e]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,11 +633,15 @@ int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int 
     if (gx < 1) gx = 1;
     if (gx > 96) gx = 96;
     if (w % 8 == 0) {
-        long gs = ((long)n * h * (w / 8) + ppb - 1) / ppb / 4;       // >= 4 row segments per thread before the atomics
+        // ~512 workgroups of (7 kernel rows x 32 channel groups) threads, each a contiguous run of row segments
+        const int gy = (cgc + 31) / 32;
+        const long nseg = (long)n * h * (w / 8);
+        long gs = 512 / gy;
         if (gs < 1) gs = 1;
-        if (gs > 146) gs = 146;                                      // x 7 kernel rows ~ 4 workgroups per CU
-        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_seg_kernel<T>, dim3((unsigned)gs, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
-                                             Ref{x, x_cs, x_co}, dw, n, h, w, c));
+        if (gs > nseg) gs = nseg;
+        const long per_block = (nseg + gs - 1) / gs;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel<T>, dim3((unsigned)((nseg + per_block - 1) / per_block), gy), dim3(224), 0, (hipStream_t)s,
+                                             Ref{dy, dy_cs, dy_co}, Ref{x, x_cs, x_co}, dw, n, h, w, c, per_block));
     } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_kernel<T>, dim3((unsigned)gx, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
                                              Ref{x, x_cs, x_co}, dw, n, h, w, c));
