@@ -447,6 +447,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// 1x1 weight gradients (16-bit, full tiles): with one tap the slab kernel above multiplies 8 MFMAs per wave and pixel
+// tile against a full staging round.  Here a workgroup owns a 128 x 128 slab of dW, a wave 2 x 2 of its 32 x 32 tiles
+// (64 accumulator registers, 32 MFMAs per wave and pixel tile from 4 transposed fragments per k-step), no halo.
+template <typename T, int GEO>
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_1x1_kernel(const WgradArgs p) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2 && GEO < 2, "16-bit types, tiles of at least 8x8 pixels");
+    constexpr int EPS = 8, ESZ = 2;
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    constexpr int ROWB = 64, PPP = 16, ITEMS = 8;                  // 16 pieces of 16 bytes per pixel and operand, 8 items per thread
+    constexpr int OP_BYTES = 4 * 128 * ROWB;                       // [4 sub-tiles][128 px][64 B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Dy = smem;
+    char* Xt = smem + OP_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = wave & 1, kw = wave >> 1;
+    const int ct = blockIdx.y;
+    const int n0 = (ct % p.co_tiles) * 128, k0 = (ct / p.co_tiles) * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // tile-independent descriptors: piece tid + it * 256 = (pixel tid / 16 + 16 it, 16-byte piece tid % 16)
+    const int pc = tid % PPP, sub = pc / 4, pin = pc % 4;
+    const int lds0 = sub * 128 * ROWB + (tid / PPP) * ROWB + pin * 16;
+    unsigned dy_off[ITEMS], x_off[ITEMS];
+    const int chd = n0 + pc * EPS, chx = k0 + pc * EPS;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int m = tid / PPP + it * 16;
+        const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
+        dy_off[it] = chd < p.cout ? (unsigned)(wg_rel_pix(img, ty, tx, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ + chd * ESZ) + WG_BIAS : 0xffffffffu;
+        x_off[it] = chx < p.cin_pad ? (unsigned)(wg_rel_pix(img, ty, tx, p.H, p.W, p.in_blk) * p.in_cs * ESZ + chx * ESZ) + WG_BIAS : 0xffffffffu;
+    }
+    float sc[EPS], sh[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+    if (p.prologue == PSSR_PRO_BN_RELU && chx < p.cin_pad) {
+        load4(p.pro_scale + chx, sc); load4(p.pro_scale + chx + 4, sc + 4);
+        load4(p.pro_shift + chx, sh); load4(p.pro_shift + chx + 4, sh + 4);
+    }
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pcol = li & 3;
+    const int fr_off = ((g >> 1) * 8 + q) * ROWB + ((g & 1) * 16 + pcol * 4) * 2;
+    const char* const dy_rd = Dy + (2 * cw) * 128 * ROWB + fr_off;
+    const char* const x_rd = Xt + (2 * kw) * 128 * ROWB + fr_off;
+    const char* const dy_base = (const char*)p.dy + (long)p.dy_co * ESZ - WG_BIAS;
+    const char* const in_base = (const char*)p.in + (long)p.in_co * ESZ - WG_BIAS;
+
+    u32x4 dy_reg[ITEMS], x_reg[ITEMS];
+#define W1_ISSUE(TILE)                                                                                            \
+    {                                                                                                             \
+        int tmi_ = (TILE);                                                                                        \
+        const int tile_x_ = tmi_ % p.tiles_x; tmi_ /= p.tiles_x;                                                  \
+        const int tile_y_ = tmi_ % p.tiles_y;                                                                     \
+        const int tile_i_ = tmi_ / p.tiles_y;                                                                     \
+        const int x0_ = tile_x_ << TWL, y0_ = tile_y_ << THL, img0_ = tile_i_ * NI;                               \
+        const __amdgpu_buffer_rsrc_t rdy_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(dy_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rin_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(in_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.in_blk) * p.in_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                    \
+            dy_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy_, (int)dy_off[it], 0, 0)); \
+            x_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin_, (int)x_off[it], 0, 0));   \
+        }                                                                                                         \
+    }
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) W1_ISSUE(tile)
+    for (; tile < p.n_tiles; tile += p.split) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            *(u32x4*)(Dy + lds0 + it * 16 * ROWB) = dy_reg[it];
+            u32x4 v = x_reg[it];
+            if (p.prologue == PSSR_PRO_BN_RELU) v = X::bn_relu(v, sc, sh);
+            else if (p.prologue == PSSR_PRO_GELU) {
+                float f[EPS];
+                X::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);
+                v = X::pack(f);
+            }
+            *(u32x4*)(Xt + lds0 + it * 16 * ROWB) = v;
+        }
+        __syncthreads();
+        const int nt = tile + p.split;
+        if (nt < p.n_tiles) W1_ISSUE(nt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            u32x4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = Frag16::load(dy_rd + a * 128 * ROWB + s * 16 * ROWB, dy_rd + a * 128 * ROWB + (s * 16 + 4) * ROWB);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = Frag16::load(x_rd + b * 128 * ROWB + s * 16 * ROWB, x_rd + b * 128 * ROWB + (s * 16 + 4) * ROWB);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) X::mma(acc[a][b], af[a], bf[b]);
+        }
+        __syncthreads();
+    }
+#undef W1_ISSUE
+    float* dst = p.dw + (p.parts > 0 ? (long)blockIdx.x * p.part_stride : 0L);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kcol = k0 + (2 * kw + b) * 32 + (lane & 31);
+            if (kcol >= p.cin_pad) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (2 * cw + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (n < p.cout) {
+                    float* qd = dst + (long)n * p.cin_pad + kcol;
+                    if (p.parts > 0) *qd = acc[a][b][e];
+                    else atomicAdd(qd, acc[a][b][e]);
+                }
+            }
+        }
+}
+
+// full tiles and offsets within the bias window: what the lean-loader kernels need (same answer at query and launch time)
+template <int GEO> bool wg_lean_ok(const WgradArgs& p) {
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    static int lean = -1;
+    if (lean < 0) { const char* e = getenv("PSSR_WGRAD_LEAN"); lean = e ? atoi(e) : 1; }
+    const bool full = p.W % TW == 0 && p.H % TH == 0 && p.N % NI == 0;
+    const long span_dy = (p.dy_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.dy_cs * 2;
+    const long span_in = (p.in_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.in_cs * 2;
+    return lean && full && span_dy < (1L << 30) && span_in < (1L << 30);
+}
+
+template <typename T, int GEO>
+int launch_1x1(WgradArgs p, hipStream_t stream, int* query) {
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    constexpr int LDS = 2 * 4 * 128 * 64;
+    p.tiles_x = cdiv(p.W, TW); p.tiles_y = cdiv(p.H, TH); p.tiles_i = cdiv(p.N, NI);
+    p.n_tiles = p.tiles_x * p.tiles_y * p.tiles_i;
+    p.co_tiles = cdiv(p.cout, 128); p.ci_tiles = cdiv(p.cin_pad, 128);
+    const int slabs = p.co_tiles * p.ci_tiles;
+    int split;
+    if (query != nullptr || p.parts > 0) {
+        split = cdiv(512, slabs);
+        if (split > p.n_tiles) split = p.n_tiles;
+        if (split < 1) split = 1;
+        if (query != nullptr) { *query = split; return PSSR_OK; }
+        PSSR_CHECK(p.parts == split, PSSR_ERR_ARG, "wgrad: dw_parts=%d but this shape needs %d (ask pssr_conv2d_wgrad_parts)", p.parts, split);
+        p.part_stride = (long)p.cout * p.cin_pad;
+    } else {
+        split = p.n_tiles / 8;
+        if (split > cdiv(1024, slabs)) split = cdiv(1024, slabs);
+        if (split < 1) split = 1;
+        if (slabs * split < 256) split = cdiv(256, slabs);
+        if (split > p.n_tiles) split = p.n_tiles;
+        p.part_stride = 0;
+    }
+    p.split = split;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad16_1x1_kernel<T, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad16_1x1_kernel<T, GEO>), dim3(split, slabs), dim3(256), LDS, stream, p);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
 template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
 int launch_t(WgradArgs p, hipStream_t stream, int* query) {
     constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
@@ -527,6 +701,13 @@ int launch_geo(const WgradArgs& a, hipStream_t s, int* query) {
 
 template <typename T>
 int launch_shape(const WgradArgs& a, hipStream_t s, int* query) {
+    if constexpr (sizeof(T) == 2) {
+        // 1x1 with both channel counts beyond one 32-wide sub-tile: the 128 x 128 slab kernel (lean-loader launches only)
+        if (a.taps == 1 && a.cout > 32 && a.cin_pad > 32) {
+            if (a.W > 8 && wg_lean_ok<0>(a)) return launch_1x1<T, 0>(a, s, query);
+            if (a.W > 4 && a.W <= 8 && wg_lean_ok<1>(a)) return launch_1x1<T, 1>(a, s, query);
+        }
+    }
     if (a.cout > 64 && a.cin_pad <= 32) return launch_geo<T, 128, 32>(a, s, query);
     if (a.cout <= 32) return launch_geo<T, 32, 128>(a, s, query);
     return launch_geo<T, 64, 64>(a, s, query);

@@ -165,45 +165,46 @@ __global__ void unpack_kernel(const float* __restrict__ dwp, int parts, long par
 // (256 >> pl) positions of 4 consecutive k  x  (1 << pl) part lanes; every thread sums its share of the parts with 16-byte
 // loads, the 9216 partial values meet in LDS, are summed over the part lanes there, and leave as runs that are
 // contiguous in the destination (when the weight has no padding / permutation: `contig`) -- no atomics, no zero pass.
+template <int TAPS>
 __global__ __launch_bounds__(256) void unpack9_kernel(const float* __restrict__ dwp, int parts, long part_stride, float* __restrict__ dw, PackMap m,
                                                       int k_pad, int accumulate, long total_nk, int contig, int pl) {
-    __shared__ float buf[1024 * 9];
+    __shared__ float buf[1024 * TAPS];
     const int tid = threadIdx.x;
     const int PL = 1 << pl, ppb = 1024 >> pl;            // part lanes, pairs per workgroup-iteration
     const int pos = tid & ((256 >> pl) - 1), plane = tid >> (8 - pl);
     for (long base = (long)blockIdx.x * ppb; base < total_nk; base += (long)gridDim.x * ppb) {
         const long i = base + pos * 4;
-        float4 v[9];
+        float4 v[TAPS];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < TAPS; ++t) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < total_nk) {
             const long n = i / k_pad;
             const int k = (int)(i - n * k_pad);
-            const float* src = dwp + n * 9 * k_pad + k;
+            const float* src = dwp + n * TAPS * k_pad + k;
             for (int q = plane; q < parts; q += PL) {
                 const float* sq = src + (long)q * part_stride;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < TAPS; ++t) {
                     const float4 a = *(const float4*)(sq + (long)t * k_pad);
                     v[t].x += a.x; v[t].y += a.y; v[t].z += a.z; v[t].w += a.w;
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            buf[(tid * 4 + 0) * 9 + t] = v[t].x; buf[(tid * 4 + 1) * 9 + t] = v[t].y;
-            buf[(tid * 4 + 2) * 9 + t] = v[t].z; buf[(tid * 4 + 3) * 9 + t] = v[t].w;
+        for (int t = 0; t < TAPS; ++t) {
+            buf[(tid * 4 + 0) * TAPS + t] = v[t].x; buf[(tid * 4 + 1) * TAPS + t] = v[t].y;
+            buf[(tid * 4 + 2) * TAPS + t] = v[t].z; buf[(tid * 4 + 3) * TAPS + t] = v[t].w;
         }
         __syncthreads();
         const long left = total_nk - base;
-        const int np = (int)(left < ppb ? left : ppb) * 9;
+        const int np = (int)(left < ppb ? left : ppb) * TAPS;
         for (int pp = tid; pp < np; pp += 256) {
             float sum = 0.f;
-            for (int l = 0; l < PL; ++l) sum += buf[l * (ppb * 9) + pp];
+            for (int l = 0; l < PL; ++l) sum += buf[l * (ppb * TAPS) + pp];
             long sidx;
-            if (contig) sidx = base * 9 + pp;
+            if (contig) sidx = base * TAPS + pp;
             else {
-                const int j = pp / 9, t = pp - j * 9;
+                const int j = pp / TAPS, t = pp - j * TAPS;
                 const long ii = base + j;
                 const long n = ii / k_pad;
                 sidx = m.src_index((int)(ii - n * k_pad), t, (int)n);
@@ -272,14 +273,19 @@ extern "C" int pssr_unpack_conv_wgrad_parts(const float* dwp, int parts, int row
     const long total = (long)cout * m.taps * k_pad;
     const int blocks = (int)((total / 4 + 255) / 256 < 4096 ? (total / 4 + 255) / 256 : 4096);
     // enough workgroups to pull the partial slabs at HBM rate: split the parts over blockIdx.y when the slab is small
-    if (mode == 0 && m.taps == 9) {
+    if (mode == 0 && (m.taps == 9 || m.taps == 1) && !m.center) {
         const long total_nk = (long)cout * k_pad;
         int pl = 0;      // part lanes: as many as keep the grid within ~2048 workgroups (and no more than there are parts)
         while (pl < 6 && (2 << pl) <= parts && (total_nk << (pl + 1)) / 1024 <= 2048) ++pl;
         const long b9 = ((total_nk << pl) + 1023) / 1024;
         const int contig = n_perm == nullptr && ci_begin == 0 && ci_count == cin && k_pad == cin;
-        hipLaunchKernelGGL(unpack9_kernel, dim3((unsigned)(b9 < 4096 ? b9 : 4096)), dim3(256), 0, (hipStream_t)stream, dwp, parts,
-                           (long)rows * m.taps * k_pad, dw, m, k_pad, accumulate, total_nk, contig, pl);
+        const dim3 grid((unsigned)(b9 < 4096 ? b9 : 4096));
+        if (m.taps == 9)
+            hipLaunchKernelGGL(unpack9_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, dwp, parts, (long)rows * m.taps * k_pad, dw, m, k_pad,
+                               accumulate, total_nk, contig, pl);
+        else
+            hipLaunchKernelGGL(unpack9_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dwp, parts, (long)rows * m.taps * k_pad, dw, m, k_pad,
+                               accumulate, total_nk, contig, pl);
         PSSR_LAUNCH_CHECK();
         return PSSR_OK;
     }

@@ -191,6 +191,9 @@ WG_CASES = [
     (2, 80, 24, 12, 20, 3),
     (40, 32, 64, 16, 16, 3),     # many pixel tiles per workgroup: exercises the prefetched tile loop
     (4, 128, 128, 32, 32, 3),
+    (4, 208, 72, 16, 32, 1),     # 1x1, 128x128 slabs with channel tails on both sides (bf16: lean-loader kernel)
+    (4, 160, 96, 8, 8, 1),       # 1x1, 8x8 tiles of 2 images
+    (6, 320, 256, 32, 32, 1),    # 1x1, several slabs and pixel tiles per workgroup
 ]
 
 
