@@ -243,7 +243,12 @@ class RDEngine(Engine):
         return c.get(name, code)
 
     def _ln_grads(self, bw, grads, ln_module, c):
-        gb = torch.empty(2 * c, dtype=torch.float32, device=bw.stat_ln.device)
+        iw, ib = self._gindex[id(ln_module.weight)], self._gindex[id(ln_module.bias)]
+        if self._goffs[ib] == self._goffs[iw] + c:
+            # weight and bias slots are adjacent in the flat gradient buffer: convert straight into them (no side copy)
+            gb = self._flat_grad[self._goffs[iw]:self._goffs[iw] + 2 * c]
+        else:
+            gb = torch.empty(2 * c, dtype=torch.float32, device=bw.stat_ln.device)
         ops.f64_to_f32(bw.stat_ln[:ops.STAT_STRIPES * 2 * c], gb)
         grads[id(ln_module.weight)], grads[id(ln_module.bias)] = gb[:c], gb[c:]
 
@@ -252,7 +257,7 @@ class RDEngine(Engine):
         s64 = bw.stat_ln[:ops.STAT_STRIPES * c]
         s64.zero_()
         ops.channel_sum_nhwc(t, npix, c, s64, code, coff=coff)
-        g = torch.empty(c, dtype=torch.float32, device=t.device)
+        g = self._gbuf(bias)               # straight into the parameter's slot of the flat gradient buffer
         ops.f64_to_f32(s64, g)
         grads[id(bias)] = g
 
@@ -345,10 +350,10 @@ class RDEngine(Engine):
         # ---- layer scale (+ ESE gate): dt, dgamma (, d fc)
         sc.A.zero_()
         ops.image_channel_dot(G, bk.t, n, hw, g, 1.0, sc.A, code, a_coff=gcoff + bk.off)
-        dgam = torch.empty(g, dtype=torch.float32, device=G.device)
+        dgam = self._gbuf(bk.mod.gamma)
         if st.ese:
             fc = lay[5].fc
-            dbfc = torch.empty(g, dtype=torch.float32, device=G.device)
+            dbfc = self._gbuf(fc.bias)
             dwfc = self._gbuf(fc.weight)
             ops.ese_bwd(sc.A, bk.gate, bk.u, bk.mod.gamma, bk.s_mean, fc.weight, hw, sc.du, dgam, dbfc, dwfc, sc.add)
             grads[id(fc.weight)], grads[id(fc.bias)] = dwfc, dbfc
