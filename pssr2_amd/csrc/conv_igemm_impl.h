@@ -37,17 +37,24 @@ template <> struct Geo<1> { static constexpr int TWL = 3, THL = 3; };   // 8 x 8
 template <> struct Geo<2> { static constexpr int TWL = 2, THL = 2; };   // 4 x 4,  8 images
 template <> struct Geo<3> { static constexpr int TWL = 1, THL = 1; };   // 2 x 2, 32 images
 template <> struct Geo<4> { static constexpr int TWL = 0, THL = 0; };   // 1 x 1, 128 images
+template <> struct Geo<5> { static constexpr int TWL = 4, THL = 4; };   // 16 x 16 = 256 pixels x 64 channels: the four waves stacked along M
 
 template <int BN, int GEO> struct Cfg {
     static constexpr int TWL = Geo<GEO>::TWL, THL = Geo<GEO>::THL;
-    static constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    // GEO 5 (BN = 64 only): 256 pixels x 64 channels per workgroup.  Per MFMA it stages 40 % fewer LDS bytes than the
+    // 128 x 128 tile (the weight slices, 3/4 of a chunk's LDS writes, are shared by twice the pixels), which is what
+    // bounds the loop: LDS write + read time of a chunk ~ its MFMA time at 128 x 128
+    static constexpr bool BIG = GEO == 5;
+    static_assert(!BIG || BN == 64, "the 256-pixel tile is built for 64 output channels");
+    static constexpr int WM = BIG ? 4 : ((BN == 32) ? 4 : 2), WN = 4 / WM;
+    static constexpr int MI = BIG ? 2 : 4 / WM, NJ = BN / (32 * WN);
+    static constexpr int MP = WM * MI * 32;                                   // output pixels per workgroup
+    static constexpr int TW = 1 << TWL, TH = 1 << THL, NI = MP >> (TWL + THL);
     static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI;
     static constexpr int A_ITEMS = (2 * HP + 255) / 256;
     static constexpr int A_BYTES = HP * 32;
     static constexpr int B_BYTES = 9 * BN * 32;
     static constexpr int B_ITEMS = (9 * BN * 2 + 255) / 256;
-    static constexpr int WM = (BN == 32) ? 4 : 2, WN = 4 / WM;
-    static constexpr int MI = 4 / WM, NJ = BN / (32 * WN);
     static constexpr int E_BYTES = WM * 32 * BN * 4;
     static constexpr int RED_BYTES = 4 * BN * 2 * 4;
     static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
@@ -1047,6 +1054,7 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     return PSSR_OK;
 }
 
+using pssr_conv::g_big_mode;
 using pssr_conv::g_flat_mode;     // 1 (default): 1x1 convolutions take conv_flat_kernel (PSSR_IGEMM_FLAT=0 disables)
 
 template <typename T, int BN, int GEO, int KC>
@@ -1098,6 +1106,9 @@ int launch(const ConvArgs& a, hipStream_t s) {
 template <typename T, int BN>
 int launch_geo(const ConvArgs& a, hipStream_t s) {
     const int w = a.W;
+    if constexpr (BN == 64 && sizeof(T) == 2) {
+        if (g_big_mode && a.taps[0] == 9 && w >= 16 && a.H >= 16) return launch_t<T, 64, 5, 9>(a, s);
+    }
     if (w > 8) return launch<T, BN, 0>(a, s);
     if (w > 4) return launch<T, BN, 1>(a, s);
     if (w > 2) return launch<T, BN, 2>(a, s);
@@ -1109,6 +1120,9 @@ template <typename T>
 int launch_bn(const ConvArgs& a, hipStream_t s) {
     if (a.cout > 64) {
         if (use_v2<T, 128>(a)) return a.taps[0] == 9 ? launch2_t<T, 128, 9>(a, s) : launch2_t<T, 128, 1>(a, s);
+        if constexpr (sizeof(T) == 2) {
+            if (g_big_mode == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
+        }
         return launch_geo<T, 128>(a, s);
     }
     if (a.cout > 32) {
