@@ -304,6 +304,23 @@ int pssr_counter_add(uint64_t* counter, uint64_t inc, pssr_stream_t stream);
 int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int h, int w, float sigma,
                        float gain, int flags, pssr_stream_t stream);
 
+/* SaltPepper (pssr/crappifiers.py:88-105): clip(x + gain, 0, 255), then `amount` (a fraction, per-tile max(N(amount, spread), 0)) of
+ * the pixels becomes 255 or 0 with equal probability; Philox stream as the other noises; flags as pssr_crappify_gaussian. */
+int pssr_crappify_saltpepper(const float* in, float* out, int tiles, int64_t per_tile, float amount, float gain, float spread,
+                             uint64_t seed, uint64_t tile_offset, int flags, const uint64_t* tile_counter, pssr_stream_t stream);
+/* Blur(spread > 0) (pssr/crappifiers.py:107-124): every tile of planes_per_tile frames is blurred with its own
+ * sigma = max(N(sigma, spread), 0) drawn from the tile's Philox stream (sigma <= 0: the tile is only offset by gain). */
+int pssr_gaussian_blur_tiles(const float* in, float* tmp, float* out, int tiles, int planes_per_tile, int h, int w, float sigma,
+                             float spread, float gain, uint64_t seed, uint64_t tile_offset, int flags, const uint64_t* tile_counter,
+                             pssr_stream_t stream);
+/* Geometry of _gen_pair (pssr/data.py:471-482) for a batch of uint8 stacks resident in HBM: centred square crop to at most
+ * `res`, np.pad(mode="reflect") up to res at the bottom / right, np.rot90 in the image plane when rot != 0, np.flip along
+ * flip_axis (0 frames, 1 rows, 2 columns, 3 rows and columns, -1 none).  The random draws (rot, flip_axis) stay on the host in the reference's
+ * order; out is uint8 [n_items][c][res][res]. */
+typedef struct pssr_gather_item { const uint8_t* src; int sh, sw, rot, flip_axis; } pssr_gather_item;
+int pssr_gen_pair_geometry_u8(const pssr_gather_item* items_dev, int n_items, uint8_t* out, int c, int res, pssr_stream_t stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * RDNet encoder of RDResUNet (pssr/models/_rdnet.py, pssr/models/rdresunet.py:84).  The 1x1 convolutions of its
  * blocks and transitions run on pssr_conv2d / pssr_conv2d_wgrad (taps = 1; PSSR_PRO_GELU / PSSR_EPI_DGRAD_GELU fuse

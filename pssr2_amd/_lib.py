@@ -53,6 +53,11 @@ class WgradDesc(C.Structure):
     ]
 
 
+class GatherItem(C.Structure):
+    """struct pssr_gather_item (include/pssr_mi355.h)"""
+    _fields_ = [("src", C.c_void_p), ("sh", C.c_int), ("sw", C.c_int), ("rot", C.c_int), ("flip_axis", C.c_int)]
+
+
 class PackItem(C.Structure):
     """struct pssr_pack_item (include/pssr_mi355.h)."""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("n_perm", c_void_p),

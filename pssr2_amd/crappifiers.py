@@ -96,6 +96,9 @@ class SaltPepper(Crappifier):
         out[flipped & ~salted] = 0
         return np.clip(out, 0, 1) * 255
 
+    def device_spec(self):
+        return ("saltpepper", float(self.intensity), float(self.gain), float(self.spread))
+
 
 class Blur(Crappifier):
     def __init__(self, intensity: float = 2, gain: float = 0, spread: float = 0):

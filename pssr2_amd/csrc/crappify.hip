@@ -194,6 +194,87 @@ __global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
+// SaltPepper (pssr/crappifiers.py:88-105 -> skimage.util.random_noise(mode="s&p")): clip(x + gain, 0, 255), then a fraction
+// `amount` of the pixels becomes 255 (salt, probability 1/2) or 0 (pepper).  Counter-based like the other noises; the
+// reference draws from an unseeded default_rng(), so there is no stream to reproduce: parity is statistical.
+__global__ void saltpepper_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, long per_tile, float amount, float gain,
+                                  float spread, uint64_t seed, uint64_t tile_offset, int flags, const uint64_t* __restrict__ tile_counter) {
+    if (tile_counter) tile_offset += tile_counter[0];
+    const long total = (long)tiles * per_tile;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tile = i / per_tile, pix = i % per_tile;
+        const Philox ph(seed, tile_offset + tile);
+        const double a = tile_intensity(ph, amount, spread);
+        const uint4 r = ph((uint64_t)pix, 0u);
+        double v = (double)in[i] + (double)gain;
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        if (u01(r.x, r.y) <= a) v = u01(r.z, r.w) <= 0.5 ? 255.0 : 0.0;
+        out[i] = (float)finish(v, flags);
+    }
+}
+
+// Blur with a per-tile sigma = max(N(intensity, spread), 0) (Blur(spread > 0): pssr/crappifiers.py:107-124 draws it per call,
+// i.e. per tile): same separable pass as blur_pass_kernel with the tile's own radius; sigma <= 0 leaves the tile unchanged.
+__global__ void blur_pass_tiles_kernel(const float* __restrict__ in, float* __restrict__ out, int tiles, int planes_per_tile, int h, int w,
+                                       float intensity, float spread, uint64_t seed, uint64_t tile_offset, int axis, float gain, int flags,
+                                       const uint64_t* __restrict__ tile_counter) {
+    if (tile_counter) tile_offset += tile_counter[0];
+    const long per_tile = (long)planes_per_tile * h * w, total = (long)tiles * per_tile;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tile = i / per_tile;
+        const Philox ph(seed, tile_offset + tile);
+        const double sigma = tile_intensity(ph, intensity, spread);
+        const int x = i % w, y = (i / w) % h;
+        const long base = i - (long)y * w - x;
+        double v = (double)in[i];
+        if (sigma > 0.0) {
+            const int r = (int)(4.0 * (double)(float)sigma + 0.5);
+            double wsum = 0.0, acc = 0.0;
+            for (int t = -r; t <= r; ++t) {
+                const double wt = exp(-0.5 / (sigma * sigma) * (double)t * t);
+                int yy = y, xx = x;
+                if (axis == 0) { yy = y + t; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy); }
+                else { xx = x + t; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx); }
+                wsum += wt; acc += wt * (double)in[base + (long)yy * w + xx];
+            }
+            v = (double)(float)(acc / wsum);
+        }
+        if (axis == 1) v = finish((double)(float)v + (double)gain, flags);
+        out[i] = (float)v;
+    }
+}
+
+// Geometry of _gen_pair (pssr/data.py:471-482): centred square crop to at most `res`, reflect padding up to `res` at the
+// bottom / right (np.pad(mode="reflect")), then np.rot90 in the (H, W) plane when rot, then np.flip along axis flip_axis
+// (0 = frames, 1 = rows, 2 = columns, 3 = rows and columns = axis (1, 2); -1 = none).  One source stack [c][sh][sw] per tile, addressed through a pointer table
+// so that stacks of different sizes can be batched; the random draws stay on the host (reference order).
+struct GatherItem { const uint8_t* src; int sh, sw, rot, flip_axis; };
+
+__global__ void gen_pair_geometry_kernel(const GatherItem* __restrict__ items, uint8_t* __restrict__ out, int c, int res) {
+    const GatherItem it = items[blockIdx.y];
+    const long per_tile = (long)c * res * res;
+    const int size = it.sh < it.sw ? (it.sh < res ? it.sh : res) : (it.sw < res ? it.sw : res);   // min(h, w, res)
+    const bool exact = it.sh == res && it.sw == res;
+    const int sx = exact ? 0 : (it.sh - size) / 2, sy = exact ? 0 : (it.sw - size) / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per_tile; i += (long)gridDim.x * blockDim.x) {
+        int ox = (int)(i % res), oy = (int)((i / res) % res), oc = (int)(i / ((long)res * res));
+        // undo flip, then rot90, to find the coordinate in the padded crop
+        if (it.flip_axis == 0) oc = c - 1 - oc;
+        if (it.flip_axis == 1 || it.flip_axis == 3) oy = res - 1 - oy;
+        if (it.flip_axis == 2 || it.flip_axis == 3) ox = res - 1 - ox;
+        int py = oy, px = ox;
+        if (it.rot) { py = ox; px = res - 1 - oy; }        // np.rot90(m)[i][j] = m[j][n - 1 - i]
+        // reflect padding (no edge repeat) beyond the crop: index p >= size maps to 2 * (size - 1) - p, periodically
+        if (size > 1) {
+            const int period = 2 * (size - 1);
+            py %= period; px %= period;
+            if (py >= size) py = period - py;
+            if (px >= size) px = period - px;
+        } else { py = 0; px = 0; }
+        out[blockIdx.y * per_tile + i] = it.src[((long)oc * it.sh + sx + py) * it.sw + sy + px];
+    }
+}
+
 static inline int grid1d(long total) { long b = (total + 255) / 256; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
 
 }  // namespace
@@ -252,6 +333,39 @@ int pssr_gaussian_blur(const float* in, float* tmp, float* out, int planes, int 
     hipLaunchKernelGGL(blur_pass_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, in, tmp, planes, h, w, sigma, 0, 0.f, 0);
     PSSR_LAUNCH_CHECK();
     hipLaunchKernelGGL(blur_pass_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, tmp, out, planes, h, w, sigma, 1, gain, flags);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_crappify_saltpepper(const float* in, float* out, int tiles, int64_t per_tile, float amount, float gain, float spread, uint64_t seed,
+                             uint64_t tile_offset, int flags, const uint64_t* tile_counter, pssr_stream_t s) {
+    PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3 && amount >= 0.f, PSSR_ERR_ARG, "crappify_saltpepper: bad args");
+    hipLaunchKernelGGL(saltpepper_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
+                       amount, gain, spread, seed, tile_offset, flags, tile_counter);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_gaussian_blur_tiles(const float* in, float* tmp, float* out, int tiles, int planes_per_tile, int h, int w, float sigma, float spread,
+                             float gain, uint64_t seed, uint64_t tile_offset, int flags, const uint64_t* tile_counter, pssr_stream_t s) {
+    PSSR_CHECK(in && tmp && out && tiles > 0 && planes_per_tile > 0 && h > 0 && w > 0 && sigma >= 0.f && spread >= 0.f && flags >= 0 && flags <= 3,
+               PSSR_ERR_ARG, "gaussian_blur_tiles: bad args");
+    const long total = (long)tiles * planes_per_tile * h * w;
+    hipLaunchKernelGGL(blur_pass_tiles_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, in, tmp, tiles, planes_per_tile, h, w, sigma,
+                       spread, seed, tile_offset, 0, 0.f, 0, tile_counter);
+    PSSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blur_pass_tiles_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)s, tmp, out, tiles, planes_per_tile, h, w, sigma,
+                       spread, seed, tile_offset, 1, gain, flags, tile_counter);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_gen_pair_geometry_u8(const pssr_gather_item* items_dev, int n_items, uint8_t* out, int c, int res, pssr_stream_t s) {
+    PSSR_CHECK(items_dev && out && n_items > 0 && n_items <= 65535 && c > 0 && res > 0, PSSR_ERR_ARG, "gen_pair_geometry: bad args");
+    static_assert(sizeof(pssr_gather_item) == sizeof(GatherItem), "pssr_gather_item layout");
+    const long per_tile = (long)c * res * res;
+    long gx = (per_tile + 255) / 256; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(gen_pair_geometry_kernel, dim3((unsigned)gx, n_items), dim3(256), 0, (hipStream_t)s, (const GatherItem*)items_dev, out, c, res);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

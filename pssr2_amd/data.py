@@ -288,9 +288,11 @@ class DevicePairGenerator:
         if kind == "poisson":
             return ops.crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, tile_counter=self.tile_counter)
         if kind == "blur":
-            if spread > 0:
-                raise NotImplementedError("Blur(spread>0) has no device path")
+            if spread > 0:      # per-tile sigma from the tile's Philox stream
+                return ops.gaussian_blur_tiles(x, intensity, spread, gain, seed, tile_offset, flags, tile_counter=self.tile_counter)
             return ops.gaussian_blur(x, intensity, gain, flags)
+        if kind == "saltpepper":
+            return ops.crappify_saltpepper(x, intensity, gain, spread, seed, tile_offset, flags, tile_counter=self.tile_counter)
         raise NotImplementedError(kind)
 
     def __call__(self, hr_u8: torch.Tensor, tile_offset: int = 0):
@@ -315,3 +317,11 @@ class DevicePairGenerator:
             else:
                 lr = self._stage(lr, spec, self.seed, tile_offset, ops.ROUND_CLIP)
         return ops.u8_to_f32(hr_u8), lr
+
+    def from_stacks(self, stacks, hr_res, rotations=None, tile_offset: int = 0):
+        """On-device ``_gen_pair`` (pssr/data.py:471-495) for a batch of uint8 stacks [C, H, W] resident in HBM: centred
+        crop / reflect pad to ``hr_res``, rot90 / flip with the (host-drawn, reference-order) ``rotations``, then the
+        Pillow-exact reduction and the crappifier.  Returns float32 (hr, lr)."""
+        from . import ops
+        rotations = [False] * len(stacks) if rotations is None else rotations
+        return self(ops.gen_pair_geometry_u8(stacks, rotations, hr_res), tile_offset)

@@ -431,3 +431,41 @@ def head_conv_bwd(g, g_scale, weight, act, dact, blk, dw, bias_sum, n, h, w, cin
     """dgrad + wgrad (+ the bias sums of the pixel-shuffle conv in front) in one pass over the activation."""
     L.check(L.lib().pssr_head_conv_bwd(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
                                        blk, L.ptr(dw), L.ptr(bias_sum), n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_bwd")
+
+
+def crappify_saltpepper(x, amount, gain, spread, seed, tile_offset, flags, out=None, tile_counter=None):
+    out = torch.empty_like(x) if out is None else out
+    tiles = x.shape[0]
+    L.check(L.lib().pssr_crappify_saltpepper(L.ptr(x), L.ptr(out), tiles, C.c_int64(x.numel() // tiles), C.c_float(amount), C.c_float(gain),
+                                             C.c_float(spread), C.c_uint64(seed), C.c_uint64(tile_offset), flags, L.ptr(tile_counter),
+                                             L.stream_ptr()), "pssr_crappify_saltpepper")
+    return out
+
+
+def gaussian_blur_tiles(x, sigma, spread, gain, seed, tile_offset, flags, tile_counter=None):
+    """x: [tiles, frames, h, w] f32; every tile is blurred with its own sigma = max(N(sigma, spread), 0)."""
+    tiles, h, w = x.shape[0], x.shape[-2], x.shape[-1]
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    L.check(L.lib().pssr_gaussian_blur_tiles(L.ptr(x), L.ptr(tmp), L.ptr(out), tiles, x.numel() // (tiles * h * w), h, w, C.c_float(sigma),
+                                             C.c_float(spread), C.c_float(gain), C.c_uint64(seed), C.c_uint64(tile_offset), flags,
+                                             L.ptr(tile_counter), L.stream_ptr()), "pssr_gaussian_blur_tiles")
+    return out
+
+
+def gen_pair_geometry_u8(stacks, rotations, res):
+    """_gen_pair's crop / reflect pad / rot90 / flip for a batch of uint8 stacks [c, h, w] resident on the device.
+    rotations: per stack ``False`` or ``[rot, axis]`` as the reference draws them (axis 1, 2 or (1, 2))."""
+    c = stacks[0].shape[0]
+    items = (L.GatherItem * len(stacks))()
+    for i, (st, rot) in enumerate(zip(stacks, rotations)):
+        if st.dtype != torch.uint8 or not st.is_cuda or st.dim() != 3 or st.shape[0] != c or not st.is_contiguous():
+            raise ValueError("gen_pair_geometry_u8 needs contiguous uint8 [c, h, w] stacks on the device")
+        axis = -1
+        if rot:
+            axis = 3 if isinstance(rot[1], (tuple, list)) else int(rot[1])
+        items[i].src, items[i].sh, items[i].sw = st.data_ptr(), st.shape[1], st.shape[2]
+        items[i].rot, items[i].flip_axis = int(bool(rot and rot[0])), axis
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(stacks[0].device)
+    out = torch.empty(len(stacks), c, res, res, dtype=torch.uint8, device=stacks[0].device)
+    L.check(L.lib().pssr_gen_pair_geometry_u8(L.ptr(table), len(stacks), L.ptr(out), c, res, L.stream_ptr()), "pssr_gen_pair_geometry_u8")
+    return out

@@ -94,3 +94,56 @@ def test_device_pair_generator_matches_host_gen_pair():
         assert lr.min() >= 0 and lr.max() <= 255 and np.array_equal(lr, np.round(lr))
         clean = lr_d.cpu().numpy()
         assert 0.5 < np.abs(lr - clean).mean() < 20
+
+
+def test_device_gen_pair_geometry_bit_exact_vs_host():
+    """On-device crop / reflect pad / rot90 / flip of _gen_pair (pssr/data.py:471-482), bit-exact against the host path for
+    stacks larger than, equal to and smaller than the target (reflect padding over more than one period included)."""
+    from pssr2_amd.data import DevicePairGenerator, _gen_pair
+    rng = np.random.default_rng(5)
+    shapes = [(2, 96, 96), (2, 64, 64), (2, 80, 120), (2, 40, 40), (2, 17, 23), (2, 64, 30)]
+    rots = [False, [True, 1], [False, 2], [True, (1, 2)], [True, 2], [False, (1, 2)]]
+    stacks = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
+    gen = DevicePairGenerator(4, None)
+    hr_d, lr_d = gen.from_stacks([torch.tensor(s).cuda() for s in stacks], 64, rots)
+    for i, (s, r) in enumerate(zip(stacks, rots)):
+        h, l = _gen_pair(s, 64, 4, r, None, None, None)
+        assert torch.equal(hr_d[i].cpu(), h), (i, shapes[i], r)
+        assert torch.equal(lr_d[i].cpu(), l), (i, shapes[i], r)
+
+
+def test_device_saltpepper_and_blur_spread():
+    """SaltPepper and Blur(spread > 0) on the device.  The reference's SaltPepper draws from an unseeded
+    default_rng, so the check is statistical: fraction of flipped pixels, salt/pepper balance, untouched pixels exact."""
+    from oracle import pairs_ref as P
+    from pssr2_amd import ops
+    from pssr2_amd.crappifiers import Blur, MultiCrappifier, SaltPepper
+    from pssr2_amd.data import DevicePairGenerator
+    x = torch.full((8, 1, 128, 128), 100.25, device="cuda")
+    out = ops.crappify_saltpepper(x, 0.05, 3.0, 0.0, seed=2, tile_offset=0, flags=0).cpu().numpy()
+    salt, pepper = (out == 255).mean(), (out == 0).mean()
+    n = out.size
+    assert abs(salt + pepper - 0.05) < 4 * np.sqrt(0.05 / n) and abs(salt - pepper) < 4 * np.sqrt(0.05 / n)
+    assert np.all((out == 255) | (out == 0) | (out == np.float32(103.25)))
+    again = ops.crappify_saltpepper(x, 0.05, 3.0, 0.0, seed=2, tile_offset=0, flags=0).cpu().numpy()
+    assert np.array_equal(out, again)                                        # counter-based: reproducible
+    two = ops.crappify_saltpepper(x[:4], 0.05, 3.0, 0.0, seed=2, tile_offset=4, flags=0).cpu().numpy()
+    assert np.array_equal(two, out[4:])                                      # independent of how tiles are batched
+    # per-tile sigma: every tile equals the fixed-sigma blur at SOME sigma near the mean; tiles differ from each other
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 255, (6, 2, 40, 40)).astype(np.float32)
+    outb = ops.gaussian_blur_tiles(torch.tensor(img).cuda(), 2.0, 0.5, 1.0, seed=9, tile_offset=0, flags=0).cpu().numpy()
+    sig = []
+    for t in range(6):
+        errs = {s: np.abs(P.gaussian_blur_nearest(img[t], s) + 1.0 - outb[t]).max() for s in np.arange(0.4, 4.0, 0.01)}
+        best = min(errs, key=errs.get)
+        sig.append(best)
+        assert errs[best] < 0.05 * 255 * 0.01 + 0.6, (t, best, errs[best])    # the grid is 0.01 wide in sigma
+    assert np.std(sig) > 0.05 and abs(np.mean(sig) - 2.0) < 1.0
+    zero = ops.gaussian_blur_tiles(torch.tensor(img).cuda(), 0.0, 0.0, 2.0, seed=9, tile_offset=0, flags=0).cpu().numpy()
+    assert np.array_equal(zero, img + 2.0)
+    # the chain runs through the device pair generator
+    hr = torch.tensor(rng.integers(0, 256, (4, 1, 128, 128), dtype=np.uint8)).cuda()
+    _, lr = DevicePairGenerator(4, MultiCrappifier(Blur(1.0, spread=0.3), SaltPepper(2.0)), seed=1)(hr)
+    lr = lr.cpu().numpy()
+    assert lr.min() >= 0 and lr.max() <= 255 and np.array_equal(lr, np.round(lr)) and 0.005 < ((lr == 0) | (lr == 255)).mean() < 0.05
