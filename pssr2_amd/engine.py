@@ -109,6 +109,14 @@ class Engine:
         self._convs = {}
         self.reducer = None          # pssr2_amd.distributed.GradReducer when data-parallel
         self._flat_grad = None
+        # weight-gradient launches (wgrad + partial-slab reduction) on a second HIP stream: nothing on the backward's
+        # dependent chain waits for them, so they fill the chip while the chain runs its tiny BatchNorm-coefficient
+        # kernels and kernel tails (PSSR_WGRAD_STREAM=0 keeps everything on the launch stream)
+        import os
+        self.side_wgrad = os.environ.get("PSSR_WGRAD_STREAM", "1") != "0"
+        self._side = None
+        self._side_on = False
+        self._pending = {}
 
     # ------------------------------------------------------------------ flat gradient buffer
     def _grad_layout(self, device):
@@ -145,6 +153,7 @@ class Engine:
         self._flat_grad.zero_()
         if self.reducer is not None:
             self.reducer.begin()
+        self._side_begin(device)
 
     def _finish_backward(self, grads):
         """Publish the gradients.  The engine owns the .grad of its parameters: a parameter without a gradient gets the
@@ -152,6 +161,7 @@ class Engine:
         existing gradient is accumulated into, as autograd would."""
         if self.reducer is not None:
             self.reducer.finish()
+        self._side_join()
         with torch.no_grad():
             for prm, view in zip(self.model.parameters(), self._gviews):
                 if not prm.requires_grad:
@@ -165,6 +175,44 @@ class Engine:
     def _gbuf(self, param):
         """Zeroed gradient slot of a parameter (a view of the flat buffer)."""
         return self._gviews[self._gindex[id(param)]]
+
+    # ------------------------------------------------------------------ second stream for the weight gradients
+    def _side_begin(self, device):
+        self._side_on = bool(self.side_wgrad) and self.reducer is None and type(self) is Engine and device.type == "cuda"
+        self._pending = {}
+        if self._side_on and self._side is None:
+            self._side = torch.cuda.Stream(device)
+
+    def _on_side(self, reads, fn):
+        """Run fn() on the side stream after everything issued so far on the launch stream; `reads` are the launch-stream
+        buffers it reads (their next writer waits for it, see _before_write)."""
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            fn()
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for b in reads:
+            self._pending[b.data_ptr()] = done
+
+    def _before_write(self, *bufs):
+        """The launch stream is about to overwrite these buffers: wait for side-stream readers still using them."""
+        if not self._side_on:
+            return
+        main = torch.cuda.current_stream()
+        for b in bufs:
+            ev = self._pending.pop(b.data_ptr(), None)
+            if ev is not None:
+                main.wait_event(ev)
+
+    def _side_join(self):
+        if self._side_on:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending = {}
 
     def _ready(self, grads, params):
         """Copy small side results into their slots and tell the reducer these parameters are final."""
@@ -299,6 +347,7 @@ class Engine:
 
         b.dz = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
         b.dy = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
+        b.dy2 = [buf(*p.dims[l], hid[l]) for l in range(Lv)] if self.side_wgrad else b.dy
         b.g = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
         b.dout = [buf(*p.dims[l], hid[l]) for l in range(Lv)]            # gradient of a block output at level l
         b.dcat = [buf(*p.dims[l], hid[l + 1] // 4 + hid[l]) for l in range(Lv - 1)]
@@ -494,19 +543,28 @@ class Engine:
         code = p.code
         esz = 4 if code == L.F32 else 2
         co_eff = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
-        dwp = ops.conv2d_wgrad_parts(dy, co_eff, src, cin_pad, taps, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
-                                     pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)
         w = conv_module.weight
         gname = id(w)
+
+        def parts():
+            return ops.conv2d_wgrad_parts(dy, co_eff, src, cin_pad, taps, n=p.n, h=hh, w=ww, dtype=code, dy_blk=dy_blk, in_blk=in_blk,
+                                          pro_scale=pro.scale if pro else None, pro_shift=pro.shift if pro else None)
         if center:
             g3 = torch.zeros(w.shape[0], w.shape[1], 3, 3, dtype=torch.float32, device=w.device)
-            ops.unpack_conv_wgrad(dwp, g3, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
+            ops.unpack_conv_wgrad(parts(), g3, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad)
             grads[gname] = g3[:, :, 1:2, 1:2].contiguous()
             return
         if gname not in grads:
             grads[gname] = self._gbuf(w)          # zeroed at the start of backward
-        # the slot was zeroed with the whole flat buffer at the start of backward: accumulate (no separate zero pass)
-        ops.unpack_conv_wgrad(dwp, grads[gname], mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad, accumulate=True)
+        slot = grads[gname]
+
+        def run():
+            # the slot was zeroed with the whole flat buffer at the start of backward: accumulate (no separate zero pass)
+            ops.unpack_conv_wgrad(parts(), slot, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad, accumulate=True)
+        if self._side_on:
+            self._on_side([dy], run)
+        else:
+            run()
 
     def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
         """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc."""
@@ -516,14 +574,17 @@ class Engine:
         npix = n * hh * ww
         count = float(npix)
         nl = len(blk.y)
-        dz, dy, g = bw.dz[lvl], bw.dy[lvl], bw.g[lvl]
+        dz, g = bw.dz[lvl], bw.g[lvl]
+        dy, dy_alt = bw.dy[lvl], (bw.dy2[lvl] if self._side_on else bw.dy[lvl])     # ping-pong: a side-stream wgrad may still read the other one
         last = blk.bn[-1]
         bn_last = module.conv[3 * (nl - 1) + 1]
+        self._before_write(dz)
         ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
         dgam, dbet = self._gbuf(bn_last.weight), self._gbuf(bn_last.bias)
         ops.bn_bwd_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
         grads[id(bn_last.weight)], grads[id(bn_last.bias)] = dgam, dbet
         grads[id(module.respass.bias)] = dbet               # d(respass bias) = sum dz = dbeta of the last BN (copied by _ready)
+        self._before_write(dy)
         ops.bn_bwd_apply(dz, blk.y[-1], last.ca, last.cb, last.cc, dy, npix, blk.c, code)
         for k in range(nl - 1, 0, -1):
             conv = module.conv[3 * k]
@@ -537,7 +598,9 @@ class Engine:
             dgam, dbet = self._gbuf(bn_prev.weight), self._gbuf(bn_prev.bias)
             ops.bn_bwd_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
             grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
-            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy, npix, blk.c, code)
+            self._before_write(dy_alt)
+            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_alt, npix, blk.c, code)
+            dy, dy_alt = dy_alt, dy
         conv0, rp = module.conv[0], module.respass
         if first:
             self._wgrad(p, grads, conv0, dy, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww)
