@@ -178,7 +178,7 @@ class Engine:
 
     # ------------------------------------------------------------------ second stream for the weight gradients
     def _side_begin(self, device):
-        self._side_on = bool(self.side_wgrad) and self.reducer is None and type(self) is Engine and device.type == "cuda"
+        self._side_on = bool(self.side_wgrad) and self.reducer is None and device.type == "cuda"
         self._pending = {}
         if self._side_on and self._side is None:
             self._side = torch.cuda.Stream(device)

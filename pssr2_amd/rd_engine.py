@@ -195,6 +195,7 @@ class RDEngine(Engine):
         # decoder working buffers, indexed by decoder block k (Engine._block_backward indexes them by blk.level)
         b.dz = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dy = [buf(*p.dims[k], hid[k]) for k in range(nd)]
+        b.dy2 = [buf(*p.dims[k], hid[k]) for k in range(nd)] if self.side_wgrad else b.dy
         b.g = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dout = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dcat = [buf(*p.dims[k], p.shuf_c[k] + m.skips[k]) for k in range(nd)]
@@ -265,10 +266,16 @@ class RDEngine(Engine):
         code = p.code
         esz = 4 if code == L.F32 else 2
         rows = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
-        dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
         w = conv_module.weight
-        grads[id(w)] = self._gbuf(w)
-        ops.unpack_conv_wgrad(dwp, grads[id(w)], mode=mode, k_pad=cin_pad, accumulate=True)     # slot zeroed at the start of backward
+        slot = grads[id(w)] = self._gbuf(w)
+
+        def run():
+            dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
+            ops.unpack_conv_wgrad(dwp, slot, mode=mode, k_pad=cin_pad, accumulate=True)     # slot zeroed at the start of backward
+        if self._side_on:
+            self._on_side([dy], run)       # second stream: see Engine._on_side / _before_write
+        else:
+            run()
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train):
@@ -357,9 +364,11 @@ class RDEngine(Engine):
             dwfc = self._gbuf(fc.weight)
             ops.ese_bwd(sc.A, bk.gate, bk.u, bk.mod.gamma, bk.s_mean, fc.weight, hw, sc.du, dgam, dbfc, dwfc, sc.add)
             grads[id(fc.weight)], grads[id(fc.bias)] = dwfc, dbfc
+            self._before_write(sc.dt)
             ops.scale_nc(G, bk.gate, bk.mod.gamma, sc.add, sc.dt, n, hw, g, code, t_coff=gcoff + bk.off)
         else:
             ops.ese_bwd(sc.A, None, None, bk.mod.gamma, None, None, hw, None, dgam, None, None, None)
+            self._before_write(sc.dt)
             ops.scale_nc(G, None, bk.mod.gamma, None, sc.dt, n, hw, g, code, t_coff=gcoff + bk.off)
         grads[id(bk.mod.gamma)] = dgam
         # ---- second 1x1 conv (input = gelu(z))
@@ -367,6 +376,7 @@ class RDEngine(Engine):
         self._wgrad1x1(p, grads, c2, sc.dt, g, 0, bk.z, bk.inter, st.h, st.w, gelu_in=True)
         s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * bk.inter]
         s64.zero_()
+        self._before_write(sc.dz)
         ops.conv2d(sc.dt, sc.dt.shape[-1], self._pw(c2, "dgrad", code, mode=1), sc.dz, bk.inter, n=n, h=st.h, w=st.w,
                    epilogue=L.EPI_DGRAD_GELU, flags=L.FLAG_STATS, aux=bk.z, stats=s64)
         sums = torch.empty(2 * bk.inter, dtype=torch.float32, device=G.device)
@@ -379,12 +389,20 @@ class RDEngine(Engine):
         # ---- LayerNorm2d
         s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * bk.c_in]
         s64.zero_()
+        self._before_write(sc.ddw)
         ops.layernorm2d_bwd(sc.dln, bk.dw, ln.weight, bk.stat[0], bk.stat[1], sc.ddw, s64, n, st.h, st.w, bk.c_in, code, c_pad=bk.c_in)
         self._ln_grads(bw, grads, ln, bk.c_in)
         # ---- depthwise 7x7
         self._bias_grad(bw, grads, dwc.bias, sc.ddw, st.npix, bk.c_in, code)
         dww = self._gbuf(dwc.weight)
-        ops.dwconv7_wgrad(sc.ddw, st.F, dww.view(bk.c_in, 49), n, st.h, st.w, bk.c_in, code, x_coff=st.coff)
+        ddw, c_in = sc.ddw, bk.c_in
+
+        def dw_run():
+            ops.dwconv7_wgrad(ddw, st.F, dww.view(c_in, 49), n, st.h, st.w, c_in, code, x_coff=st.coff)
+        if self._side_on:
+            self._on_side([ddw], dw_run)
+        else:
+            dw_run()
         grads[id(dwc.weight)] = dww
         ops.dwconv7_pack(dwc.weight, bk.wpf, flip=True)
         ops.dwconv7(sc.ddw, bk.wpf, None, G, n, st.h, st.w, bk.c_in, code, out_coff=gcoff, accumulate=True)
