@@ -412,6 +412,17 @@ int pssr_sliding_tiles_u8(const uint8_t* sheet, float* tiles, int c, int h, int 
 int pssr_patch_tiles_u8(const uint8_t* tiles, uint8_t* sheet, int c, int n_rows, int n_cols, int size, int overlap, int margin,
                         pssr_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * normalize_preds (pssr/util.py:139-191) for uint8 image pairs of equal size resident in HBM: percentile window
+ * of the ground truth, mean removal, covariance amplitude of the prediction, rescaling to the ground truth's intensity, clip
+ * and uint8 cast -- bit-exact with the reference's numpy float32 / float64 arithmetic (float32 percentile lerp and pairwise
+ * summation reproduced; see csrc/metrics.hip).  Images are [n_images][pixels_per_image]; workspace of
+ * n_images * pssr_normalize_preds_workspace_bytes(pixels_per_image) bytes. */
+int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image);
+int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat, uint8_t* hr_norm, uint8_t* hr_hat_norm, int n_images,
+                            int64_t pixels_per_image, float pmin, float pmax, void* workspace, pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

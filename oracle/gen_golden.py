@@ -325,6 +325,27 @@ def gen_post(pssr):
     np.savez_compressed(OUT / "post.npz", **out)
 
 
+def gen_metrics(pssr):
+    """normalize_preds (pssr/util.py:139-191) on uint8 pairs of equal shape (the path test_metrics / predict_images(norm=True)
+    take: pssr/predict.py:186-190): percentile window, mean removal, covariance amplitude, rescale, clip, uint8 cast."""
+    from pssr.util import normalize_preds
+    rng = np.random.default_rng(33)
+    out = {}
+    for name, shape in {"a": (2, 1, 64, 64), "b": (1, 96, 80), "c": (3, 48, 48)}.items():
+        hr = rng.integers(0, 256, size=shape).astype(np.float64)
+        k = np.ones(5) / 5
+        smooth = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), -1, hr)
+        smooth = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), -2, smooth)
+        hr_u8 = np.clip(smooth * 1.3 - 20, 0, 255).astype(np.uint8)
+        hat_u8 = np.clip(smooth * 0.8 + 25 + rng.normal(0, 6, size=shape), 0, 255).astype(np.uint8)
+        a, b = normalize_preds(hr_u8, hat_u8)
+        out[f"{name}_hr"], out[f"{name}_hat"], out[f"{name}_hr_norm"], out[f"{name}_hat_norm"] = hr_u8, hat_u8, a, b
+    hr_u8, hat_u8 = out["a_hr"], out["a_hat"]
+    a, b = normalize_preds(hr_u8, hat_u8, pmin=2.0, pmax=98.0)
+    out["a_p2_hr_norm"], out["a_p2_hat_norm"] = a, b
+    np.savez_compressed(OUT / "metrics.npz", **out)
+
+
 def gen_train_trace(pssr):
     """2-epoch train_paired trace on an in-memory dataset (MSELoss): pins step order,
     train/eval toggling, log cadence and the returned loss lists (pssr/train.py:19-166)."""
@@ -366,7 +387,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)   # deterministic summation order for the fixtures
     pssr = import_reference()
     only = sys.argv[1:]
-    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_train_trace):
+    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_metrics, gen_train_trace):
         if only and fn.__name__ not in only:
             continue
         fn(pssr)

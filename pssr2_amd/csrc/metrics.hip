@@ -1,0 +1,201 @@
+// normalize_preds (pssr/util.py:139-191) for uint8 image pairs of equal size, bit-exact with the reference's numpy float32 /
+// float64 arithmetic.  Both inputs are bytes, so every per-pixel quantity is a 256-entry table (normalised value, mean-removed
+// value, rescaled value, output byte); what has to be reproduced exactly is
+//   * np.percentile's float32 virtual index + lerp on the order statistics (from a histogram),
+//   * numpy's float32 summation for np.mean / np.var of the float32 images, in pixel order: buffer-sized pieces of 8192
+//     elements accumulated in order, each summed PAIRWISE (blocks of <= 128 elements with 8 accumulators, halves rounded down
+//     to a multiple of 8),
+// while the float64 parts (np.cov, the prediction's rescaling) are insensitive to summation order at uint8 resolution.
+// One workgroup per image.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NPY_BUF = 8192;      // numpy's default ufunc buffer size in elements: the granularity of its reductions
+
+struct Leaf { int start, len; };
+
+// numpy pairwise_sum: split until n <= 128 (explicit stacks: device recursion depth is not something to rely on)
+__device__ void build_leaves(int lo0, int n0, Leaf* leaves, int& count) {
+    int st_lo[48], st_n[48], sp = 0;
+    st_lo[sp] = lo0; st_n[sp] = n0; ++sp;
+    while (sp) {
+        --sp;
+        const int lo = st_lo[sp], n = st_n[sp];
+        if (n <= 128) { leaves[count].start = lo; leaves[count].len = n; ++count; continue; }
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        st_lo[sp] = lo + n2; st_n[sp] = n - n2; ++sp;       // right half (popped after the left one)
+        st_lo[sp] = lo; st_n[sp] = n2; ++sp;
+    }
+}
+__device__ float combine_leaves(int n_total, const float* sums, int& idx) {
+    int fn[48], stage[48], sp = 0;
+    float left[48], ret = 0.f;
+    fn[0] = n_total; stage[0] = 0; sp = 1;
+    while (sp) {
+        const int t = sp - 1;
+        if (fn[t] <= 128) { ret = sums[idx++]; --sp; continue; }
+        int n2 = fn[t] / 2;
+        n2 -= n2 % 8;
+        if (stage[t] == 0) { stage[t] = 1; fn[sp] = n2; stage[sp] = 0; ++sp; }
+        else if (stage[t] == 1) { left[t] = ret; stage[t] = 2; fn[sp] = fn[t] - n2; stage[sp] = 0; ++sp; }
+        else { ret = __fadd_rn(left[t], ret); --sp; }
+    }
+    return ret;
+}
+template <class F>
+__device__ float leaf_sum(int start, int n, F val) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, val(start + i));
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = val(start + j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], val(start + i + j));
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])), __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < n; ++i) res = __fadd_rn(res, val(start + i));
+    return res;
+}
+// whole-image float32 pairwise sum of val(i), i in [0, n): result broadcast through *shared_out
+template <class F>
+__device__ float pairwise_f32(int n, const Leaf* leaves, int n_leaves, float* sums, F val, float* shared_out) {
+    for (int l = threadIdx.x; l < n_leaves; l += NT) sums[l] = leaf_sum(leaves[l].start, leaves[l].len, val);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // numpy's reduction walks the array in buffer-sized pieces (np.getbufsize() = 8192 elements): result = 0, then
+        // result += pairwise(piece) for each piece in order
+        int idx = 0;
+        float acc = 0.f;
+        for (int c0 = 0; c0 < n; c0 += NPY_BUF) acc = __fadd_rn(acc, combine_leaves(n - c0 < NPY_BUF ? n - c0 : NPY_BUF, sums, idx));
+        *shared_out = acc;
+    }
+    __syncthreads();
+    const float r = *shared_out;
+    __syncthreads();
+    return r;
+}
+__device__ double block_sum_f64(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+// np.percentile(float32 array, p) with method "linear": float32 quantile, virtual index, gamma and lerp
+__device__ float percentile_f32(const int* cum /* inclusive cumulative histogram */, int n, float p) {
+    const float q = __fdiv_rn(p, 100.f);
+    const float vi = __fmul_rn((float)(n - 1), q);          // numpy's "linear" method: (n - 1) * q in the array's dtype
+    long lo, hi;
+    if (vi >= (float)(n - 1)) { lo = hi = n - 1; }
+    else if (vi < 0.f) { lo = hi = 0; }
+    else { lo = (long)floorf(vi); hi = lo + 1; }
+    auto order_stat = [&](long k) { int v = 0; while (cum[v] <= k) ++v; return (float)v; };
+    const float a = order_stat(lo), b = order_stat(hi);
+    const float t = __fsub_rn(vi, floorf(vi));
+    const float d = __fsub_rn(b, a);
+    if (t >= 0.5f) return __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.f, t)));
+    return __fadd_rn(a, __fmul_rn(d, t));
+}
+
+__global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __restrict__ hr_all, const uint8_t* __restrict__ hat_all,
+                                                             uint8_t* __restrict__ out_hr_all, uint8_t* __restrict__ out_hat_all, int n,
+                                                             float pmin, float pmax, char* __restrict__ ws_all, long ws_per_image) {
+    __shared__ int hist[256], hist2[256], cum[256];
+    __shared__ float hn[256], hn2[256], a_tab[256], hat2[256];
+    __shared__ double b_tab[256];
+    __shared__ unsigned char out_a[256], out_b[256];
+    __shared__ double red[NT];
+    __shared__ float bc;
+    __shared__ int n_leaves_s;
+    const uint8_t* hr = hr_all + (long)blockIdx.x * n;
+    const uint8_t* hat = hat_all + (long)blockIdx.x * n;
+    Leaf* leaves = (Leaf*)(ws_all + (long)blockIdx.x * ws_per_image);
+    float* sums = (float*)(leaves + (n / 32 + 16));
+    const int tid = threadIdx.x;
+    hist[tid] = 0; hist2[tid] = 0;
+    if (tid == 0) {
+        int c = 0;
+        for (int c0 = 0; c0 < n; c0 += NPY_BUF) build_leaves(c0, n - c0 < NPY_BUF ? n - c0 : NPY_BUF, leaves, c);
+        n_leaves_s = c;
+    }
+    __syncthreads();
+    const int n_leaves = n_leaves_s;
+    for (int i = tid; i < n; i += NT) { atomicAdd(&hist[hr[i]], 1); atomicAdd(&hist2[hat[i]], 1); }
+    __syncthreads();
+    if (tid == 0) { int c = 0; for (int v = 0; v < 256; ++v) { c += hist[v]; cum[v] = c; } }
+    __syncthreads();
+    // ---- hr side, all float32 (pssr/util.py:165-183)
+    const float base_max = percentile_f32(cum, n, pmax);
+    const float base_mean = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return (float)hr[i]; }, &bc), (float)n);
+    const float x_min = percentile_f32(cum, n, pmin), x_max = base_max;
+    const float denom = __fadd_rn(__fsub_rn(x_max, x_min), 1e-20f);
+    hn[tid] = __fdiv_rn(__fsub_rn((float)tid, x_min), denom);
+    __syncthreads();
+    const float mean_hn = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return hn[hr[i]]; }, &bc), (float)n);
+    hn2[tid] = __fsub_rn(hn[tid], mean_hn);
+    const float mean_hat = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return (float)hat[i]; }, &bc), (float)n);
+    hat2[tid] = __fsub_rn((float)tid, mean_hat);
+    __syncthreads();
+    int vmin = 0;
+    while (hist[vmin] == 0) ++vmin;
+    const float mn = hn2[vmin];                                        // hr_norm.min(): the map x -> hn2 is monotone
+    // np.var(hat2) in float32: mean (pairwise), deviations, squares, pairwise sum / n
+    const float m2 = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return hat2[hat[i]]; }, &bc), (float)n);
+    const float var_hat = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { const float d = __fsub_rn(hat2[hat[i]], m2); return __fmul_rn(d, d); }, &bc), (float)n);
+    // np.cov(hat2, hn2)[0, 1] in float64 (order-insensitive at this resolution)
+    double s_h = 0.0, s_n = 0.0;
+    for (int i = tid; i < n; i += NT) { s_h += (double)hat2[hat[i]]; s_n += (double)hn2[hr[i]]; }
+    const double avg_h = block_sum_f64(s_h, red) / n, avg_n = block_sum_f64(s_n, red) / n;
+    double s_c = 0.0;
+    for (int i = tid; i < n; i += NT) s_c += ((double)hat2[hat[i]] - avg_h) * ((double)hn2[hr[i]] - avg_n);
+    const double cov = block_sum_f64(s_c, red) / (double)(n - 1);
+    const double amp = cov / (double)var_hat;
+    // ---- rescale to the initial intensity (pssr/util.py:181-184)
+    a_tab[tid] = __fmul_rn(__fsub_rn(hn2[tid], mn), base_max);
+    b_tab[tid] = (amp * (double)hat2[tid] - (double)mn) * (double)base_max;
+    __syncthreads();
+    const float a_mean = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return a_tab[hr[i]]; }, &bc), (float)n);
+    double s_b = 0.0;
+    for (int i = tid; i < n; i += NT) s_b += b_tab[hat[i]];
+    const double b_mean = block_sum_f64(s_b, red) / n;
+    const float a_div = __fdiv_rn(a_mean, base_mean);
+    const double b_div = b_mean / (double)base_mean;
+    {
+        float a = __fdiv_rn(a_tab[tid], a_div);
+        a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
+        out_a[tid] = (unsigned char)a;
+        double b = b_tab[tid] / b_div;
+        b = b < 0.0 ? 0.0 : (b > 255.0 ? 255.0 : b);
+        out_b[tid] = (unsigned char)b;
+    }
+    __syncthreads();
+    uint8_t* out_hr = out_hr_all + (long)blockIdx.x * n;
+    uint8_t* out_hat = out_hat_all + (long)blockIdx.x * n;
+    for (int i = tid; i < n; i += NT) { out_hr[i] = out_a[hr[i]]; out_hat[i] = out_b[hat[i]]; }
+}
+
+}  // namespace
+
+extern "C" int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image) {
+    return ((pixels_per_image / 32 + 16) * (int64_t)(sizeof(Leaf) + sizeof(float)) + 15) / 16 * 16;
+}
+
+extern "C" int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat, uint8_t* hr_norm, uint8_t* hr_hat_norm, int n_images,
+                                       int64_t pixels_per_image, float pmin, float pmax, void* workspace, pssr_stream_t s) {
+    PSSR_CHECK(hr && hr_hat && hr_norm && hr_hat_norm && workspace && n_images > 0, PSSR_ERR_ARG, "normalize_preds: null pointer / no images");
+    PSSR_CHECK(pixels_per_image >= 2 && pixels_per_image < (1L << 24), PSSR_ERR_ARG, "normalize_preds: %ld pixels per image (2 .. 2^24 - 1)", (long)pixels_per_image);
+    PSSR_CHECK(pmin >= 0.f && pmax <= 100.f && pmin <= pmax, PSSR_ERR_ARG, "normalize_preds: percentiles");
+    hipLaunchKernelGGL(normalize_preds_kernel, dim3(n_images), dim3(NT), 0, (hipStream_t)s, hr, hr_hat, hr_norm, hr_hat_norm, (int)pixels_per_image,
+                       pmin, pmax, (char*)workspace, (long)pssr_normalize_preds_workspace_bytes(pixels_per_image));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}

@@ -469,3 +469,19 @@ def gen_pair_geometry_u8(stacks, rotations, res):
     out = torch.empty(len(stacks), c, res, res, dtype=torch.uint8, device=stacks[0].device)
     L.check(L.lib().pssr_gen_pair_geometry_u8(L.ptr(table), len(stacks), L.ptr(out), c, res, L.stream_ptr()), "pssr_gen_pair_geometry_u8")
     return out
+
+
+def normalize_preds_u8(hr, hr_hat, pmin=0.1, pmax=99.9):
+    """uint8 device tensors [..., H, W] of equal shape -> (hr_norm, hr_hat_norm) uint8, as pssr.util.normalize_preds (bit-exact)."""
+    if hr.dtype != torch.uint8 or hr_hat.dtype != torch.uint8 or hr.shape != hr_hat.shape or not hr.is_cuda:
+        raise ValueError("normalize_preds_u8 needs two uint8 device tensors of the same shape")
+    hr, hr_hat = hr.contiguous(), hr_hat.contiguous()
+    px = hr.shape[-1] * hr.shape[-2]
+    n = hr.numel() // px
+    lib = L.lib()
+    lib.pssr_normalize_preds_workspace_bytes.restype = C.c_int64
+    ws = torch.empty(n * lib.pssr_normalize_preds_workspace_bytes(C.c_int64(px)), dtype=torch.uint8, device=hr.device)
+    a, b = torch.empty_like(hr), torch.empty_like(hr_hat)
+    L.check(lib.pssr_normalize_preds_u8(L.ptr(hr), L.ptr(hr_hat), L.ptr(a), L.ptr(b), n, C.c_int64(px), C.c_float(pmin), C.c_float(pmax), L.ptr(ws),
+                                        L.stream_ptr()), "pssr_normalize_preds_u8")
+    return a, b

@@ -39,8 +39,6 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
     batch_size = 1 if batch_size is None else batch_size
     if norm and dataset.is_lr:
         raise ValueError("Dataset must be paired with high-low-resolution images for normalization.")
-    if norm:
-        raise NotImplementedError("normalize_preds (SURVEY.md §8f-3) is not part of the MI355X hot path yet")
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
     callbacks, callback_locals = _get_callbacks(callbacks)
@@ -62,6 +60,9 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
             lr = item if dataset.is_lr else item[1]
             lr = lr.to(device)
             hr_hat = _pred_array(model(lr))
+            if norm:      # pssr/predict.py:63-64: intensities matched to the ground truth of the paired dataset
+                from .util import normalize_preds
+                _, hr_hat = normalize_preds(_pred_array(item[0].to(device)), hr_hat)
             crop_res = dataset.crop_res if not dataset.is_lr else dataset.crop_res * (hr_hat.shape[-1] // lr.shape[-1])
             hr_hat = hr_hat[:, :, :crop_res, :crop_res]
             for batch_idx, image_idx in enumerate(range(cur_idx, min(cur_idx + batch_size, first + len(idx)))):
@@ -116,3 +117,60 @@ def predict_sheet(model: nn.Module, sheet, tile_res: int = 128, overlap: int = 3
     # upstream passes overlap*lr_scale and the raw margin to _patch_images (pssr/util.py:99)
     out = ops.patch_tiles_u8(preds, n_rows, n_cols, overlap * scale, margin)
     return out.cpu().numpy() if to_numpy else out
+
+
+def test_metrics(model: nn.Module, dataset: Dataset, device: str = "cpu", metrics=("mse", "pixel", "psnr", "ssim"), avg: bool = True,
+                 norm: bool = True, callbacks=None):
+    r"""Image restoration metrics of predicted vs ground truth images over ``dataset.val_idx`` (pssr/predict.py:144-211): same
+    arguments and return value.  Prediction, uint8 cast and (``norm``) intensity normalisation run on the MI355X; ``psnr`` and
+    ``ssim`` follow scikit-image's definitions (10 log10(255^2 / mse); uniform 7x7 windows, sample covariance) in float64.
+    Like the reference (pssr/predict.py:180) every iteration evaluates ``dataset[0]``."""
+    import math
+    import numpy as np
+    from .util import normalize_preds, pixel_metric
+    callbacks, callback_locals = _get_callbacks(callbacks)
+    image_range = 255
+    metrics = [metrics] if type(metrics) is str else list(metrics)
+    out = {m: [] for m in metrics}
+    model.to(device)
+    model.eval()
+
+    def _ssim(a, b):
+        from scipy.ndimage import uniform_filter
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        n = 49
+        ux, uy = uniform_filter(a, 7), uniform_filter(b, 7)
+        vx = n / (n - 1) * (uniform_filter(a * a, 7) - ux * ux)
+        vy = n / (n - 1) * (uniform_filter(b * b, 7) - uy * uy)
+        vxy = n / (n - 1) * (uniform_filter(a * b, 7) - ux * uy)
+        c1, c2 = (0.01 * image_range) ** 2, (0.03 * image_range) ** 2
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+        return float(s[3:-3, 3:-3].mean())
+
+    with torch.no_grad():
+        for _ in tqdm(dataset.val_idx):
+            hr, lr = dataset[0]
+            hr, lr = hr.to(device).unsqueeze(0), lr.to(device).unsqueeze(0)
+            hr_hat = model(lr)
+            hr, hr_hat = _pred_array(hr), _pred_array(hr_hat)
+            crop_res = dataset.crop_res if not dataset.is_lr else dataset.crop_res * (hr_hat.shape[-1] // lr.shape[-1])
+            hr, hr_hat = hr[:, :, :crop_res, :crop_res], hr_hat[:, :, :crop_res, :crop_res]
+            if norm:
+                hr, hr_hat = normalize_preds(np.ascontiguousarray(hr), np.ascontiguousarray(hr_hat))
+            for i in range(len(hr)):
+                mse = float(np.mean((hr[i] / image_range - hr_hat[i] / image_range) ** 2))
+                if "mse" in out:
+                    out["mse"].append(mse)
+                if "pixel" in out:
+                    out["pixel"].append(pixel_metric(mse, image_range))
+                if "psnr" in out:
+                    err = float(np.mean((hr[i].astype(np.float64) - hr_hat[i].astype(np.float64)) ** 2))
+                    out["psnr"].append(10 * math.log10(image_range ** 2 / err) if err > 0 else float("inf"))
+                if "ssim" in out:
+                    out["ssim"].append(_ssim(hr[i].squeeze(), hr_hat[i].squeeze()))
+            for i, callback in enumerate(callbacks):
+                callback(locals()) if callback_locals[i] else callback()
+    return {m: (sum(v) / len(v) if avg else v) for m, v in out.items()}
+
+
+test_metrics.__test__ = False      # a library function, not a pytest test (the reference's conftest deselects it the same way)

@@ -1,0 +1,78 @@
+"""normalize_preds on the device (csrc/metrics.hip) vs the reference's own outputs (tests/golden/metrics.npz) and,
+at sizes the fixtures do not hold, vs the pinned numpy restatement (oracle/metrics_ref.py): bit-exact uint8."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_normalize_preds_bit_exact_vs_reference_fixture(golden):
+    from pssr2_amd import ops
+    g = golden("metrics.npz")
+    for n in "abc":
+        a, b = ops.normalize_preds_u8(torch.tensor(g[f"{n}_hr"]).cuda(), torch.tensor(g[f"{n}_hat"]).cuda())
+        np.testing.assert_array_equal(a.cpu().numpy(), g[f"{n}_hr_norm"])
+        np.testing.assert_array_equal(b.cpu().numpy(), g[f"{n}_hat_norm"])
+    a, b = ops.normalize_preds_u8(torch.tensor(g["a_hr"]).cuda(), torch.tensor(g["a_hat"]).cuda(), pmin=2.0, pmax=98.0)
+    np.testing.assert_array_equal(a.cpu().numpy(), g["a_p2_hr_norm"])
+    np.testing.assert_array_equal(b.cpu().numpy(), g["a_p2_hat_norm"])
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512), (3, 100, 37), (1, 9, 13), (2, 1, 256, 320)])
+def test_normalize_preds_bit_exact_vs_oracle(shape):
+    from oracle import metrics_ref as M
+    from pssr2_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    base = rng.normal(120, 40, size=shape)
+    hr = np.clip(base + rng.normal(0, 5, size=shape), 0, 255).astype(np.uint8)
+    hat = np.clip(0.7 * base + 30 + rng.normal(0, 9, size=shape), 0, 255).astype(np.uint8)
+    want_a, want_b = M.normalize_preds(hr, hat)
+    a, b = ops.normalize_preds_u8(torch.tensor(hr).cuda(), torch.tensor(hat).cuda())
+    np.testing.assert_array_equal(a.cpu().numpy(), want_a)
+    np.testing.assert_array_equal(b.cpu().numpy(), want_b)
+
+
+def test_normalize_preds_argument_checks():
+    from pssr2_amd import ops
+    x = torch.zeros(1, 8, 8, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.normalize_preds_u8(x, x.float())
+    with pytest.raises(RuntimeError, match="percentiles"):
+        ops.normalize_preds_u8(x, x, pmin=60.0, pmax=40.0)
+
+
+def test_normalize_preds_api_and_drivers():
+    """pssr2_amd.util.normalize_preds (numpy in / numpy out like the reference), predict_images(norm=True) on a paired dataset and
+    test_metrics (pssr/predict.py:144-211: the reference's own smoke tests check only that these run and the result sizes)."""
+    from oracle import metrics_ref as M
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import ArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images, test_metrics
+    from pssr2_amd.util import normalize_preds
+    rng = np.random.default_rng(4)
+    hr = rng.integers(0, 256, size=(2, 1, 64, 64), dtype=np.uint8)
+    hat = np.clip(hr.astype(np.int32) // 2 + 40 + rng.integers(-9, 10, size=hr.shape), 0, 255).astype(np.uint8)
+    a, b = normalize_preds(hr, hat)
+    wa, wb = M.normalize_preds(hr, hat)
+    assert a.dtype == np.uint8 and a.shape == hr.shape
+    np.testing.assert_array_equal(a, wa)
+    np.testing.assert_array_equal(b, wb)
+    with pytest.raises(ValueError):
+        normalize_preds(hr, hat[0])
+    with pytest.raises(NotImplementedError):
+        normalize_preds(hr, hat[..., :32, :32])
+    torch.manual_seed(0)
+    model = ResUNet(hidden=[16, 32])
+    images = rng.integers(0, 256, size=(6, 1, 64, 64), dtype=np.uint8)
+    ds = ArrayDataset(images, hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(5), val_split=0.5, rotation=False)
+    plain = predict_images(model, ds, device="cuda", batch_size=2, out_dir=None)
+    normed = predict_images(model, ds, device="cuda", batch_size=2, out_dir=None, norm=True)
+    assert plain.keys() == normed.keys() and len(plain) == len(ds.val_idx)
+    assert all(v.dtype == np.uint8 and v.shape == (1, 64, 64) for v in normed.values())
+    assert any(not np.array_equal(plain[k], normed[k]) for k in plain)          # an untrained net is far from the ground truth's intensities
+    res = test_metrics(model, ds, device="cuda")
+    assert set(res) == {"mse", "pixel", "psnr", "ssim"} and all(np.isfinite(v) for v in res.values())
+    per = test_metrics(model, ds, device="cuda", metrics=["psnr", "ssim"], avg=False, norm=False)
+    assert len(per["psnr"]) == len(ds.val_idx) and -1.0 <= per["ssim"][0] <= 1.0
