@@ -189,3 +189,63 @@ def normalize_preds(hr, hr_hat, pmin: float = 0.1, pmax: float = 99.9):
         raise ValueError("images need at least 2 dimensions")
     a2, b2 = ops.normalize_preds_u8(a.to(dev).reshape(-1, *shape[-2:]), b.to(dev).reshape(-1, *shape[-2:]), pmin, pmax)
     return a2.reshape(shape).cpu().numpy(), b2.reshape(shape).cpu().numpy()
+
+
+def _sort_tiles(name: str):
+    """Sort key of tile names ``{sheet}_{tile}_{slice}[.ext]`` (pssr/util.py:110-114): slice first, then tile."""
+    if "." not in name:
+        name += "."
+    parts = name.replace(".", "_").split("_")
+    return int(parts[-2]), int(parts[-3])
+
+
+def reassemble_sheets(pred_path, lr_path, lr_scale: int, overlap: int = 0, margin: int = 0, out_dir: str = "sheets"):
+    r"""Reassembles image sheets from the tiles predicted for a sliding dataset (pssr/util.py:54-108): same arguments, file naming
+    and return value.  ``pred_path`` is a directory of tile images or the dict returned by ``predict_images``; the overlap-averaged
+    stitching (with ``margin`` trimming) runs on the MI355X (``pssr_patch_tiles_u8``, bit-exact with ``_patch_images`` + the
+    uint8 cast).  Multi-frame sheets are written through Pillow (the reference uses tifffile)."""
+    import glob
+    import os
+    import numpy as np
+    from PIL import Image
+    from . import ops
+    if margin > overlap:
+        raise ValueError(f"The value of margin cannot be greater than overlap. Given {margin} and {overlap} respectively.")
+    sheet_files = glob.glob(f"{lr_path}/*.tif", recursive=True)
+    if len(sheet_files) == 0:
+        raise FileExistsError("No files exist in lr_path.")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+
+    def frames(img):       # pssr/data.py:640-647 (_frame_channel, mode "L")
+        return np.stack([np.asarray(f.convert("L"), dtype=np.uint8) for f in _iter_frames(img)])
+
+    def _iter_frames(img):
+        for i in range(getattr(img, "n_frames", 1)):
+            img.seek(i)
+            yield img
+
+    outs = []
+    for sheet in sheet_files:
+        stem = sheet.split("/")[-1].split(".")[0]
+        if type(pred_path) is dict:
+            files = sorted([f for f in pred_path if "_".join(f.split("_")[:-2]) == stem], key=_sort_tiles)
+            batched = np.asarray([np.asarray(pred_path[f]).squeeze() for f in files])
+        else:
+            files = sorted(glob.glob(f"{pred_path}/{stem}*"), key=_sort_tiles)
+            batched = np.asarray([frames(Image.open(f)).squeeze() for f in files])
+        lr_shape = frames(Image.open(sheet)).shape
+        size = batched.shape[1]
+        n_rows = (lr_shape[1] * lr_scale - size) // (size - overlap * lr_scale) + 1
+        n_cols = (lr_shape[2] * lr_scale - batched.shape[2]) // (batched.shape[2] - overlap * lr_scale) + 1
+        per = n_rows * n_cols
+        tiles = torch.as_tensor(np.ascontiguousarray(batched.astype(np.uint8))).cuda()
+        image = np.stack([ops.patch_tiles_u8(tiles[i * per:(i + 1) * per, None].contiguous(), n_rows, n_cols, overlap * lr_scale, margin)[0].cpu().numpy()
+                          for i in range(batched.shape[0] // per)])
+        if out_dir:
+            ims = [Image.fromarray(f) for f in image]
+            ims[0].save(f"{out_dir}/{stem}.tif", save_all=len(ims) > 1, append_images=ims[1:])
+        else:
+            outs.append(image)
+    if out_dir is None:
+        return outs

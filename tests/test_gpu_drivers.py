@@ -123,3 +123,40 @@ def test_predict_sheet_matches_tile_pipeline():
     np.testing.assert_array_equal(got[0], want)
     with pytest.raises(ValueError, match="margin"):
         predict_sheet(model, sheet, tile_res=tile, overlap=4, margin=5)
+
+
+def test_reassemble_sheets_matches_reference_stitching(tmp_path):
+    """reassemble_sheets (pssr/util.py:54-108) from the dict of predict_images and from tile files: the device stitching equals
+    the host restatement of _patch_images + uint8 cast (itself pinned by post.npz), two sheets, a margin."""
+    from PIL import Image
+    from pssr2_amd.data import SlidingArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images
+    from pssr2_amd.util import _patch_images, reassemble_sheets
+    rng = np.random.default_rng(11)
+    sheets = [rng.integers(0, 256, size=(1, 104, 88), dtype=np.uint8), rng.integers(0, 256, size=(1, 104, 88), dtype=np.uint8)]
+    (tmp_path / "lr").mkdir()
+    for i, s in enumerate(sheets):
+        Image.fromarray(s[0]).save(tmp_path / "lr" / f"sheet{i}.tif")
+    torch.manual_seed(1)
+    model = ResUNet(hidden=[16, 32])
+    tile, ov, mg = 32, 8, 3
+    ds = SlidingArrayDataset(sheets, hr_res=tile, overlap=ov)
+    preds = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    got = reassemble_sheets(preds, str(tmp_path / "lr"), 4, overlap=ov, margin=mg, out_dir=None)
+    n_rows, n_cols = (104 - tile) // (tile - ov) + 1, (88 - tile) // (tile - ov) + 1
+    assert len(got) == 2
+    stems = sorted(p.stem for p in (tmp_path / "lr").glob("*.tif"))
+    import glob
+    order = [f.split("/")[-1].split(".")[0] for f in glob.glob(f"{tmp_path / 'lr'}/*.tif")]
+    for sheet_name, image in zip(order, got):
+        batched = np.asarray([preds[f"{sheet_name}_{t}_0"].squeeze() for t in range(n_rows * n_cols)])
+        want = np.asarray(_patch_images(batched, n_cols, n_rows, ov * 4, mg), dtype=np.uint8)
+        assert image.shape == (1, *want.shape)
+        np.testing.assert_array_equal(image[0], want)
+    predict_images(model, ds, device="cuda", batch_size=6, out_dir=str(tmp_path / "tiles"))
+    reassemble_sheets(str(tmp_path / "tiles"), str(tmp_path / "lr"), 4, overlap=ov, margin=mg, out_dir=str(tmp_path / "out"))
+    for sheet_name, image in zip(order, got):
+        np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "out" / f"{sheet_name}.tif")), image[0])
+    with pytest.raises(ValueError, match="margin"):
+        reassemble_sheets(preds, str(tmp_path / "lr"), 4, overlap=2, margin=3, out_dir=None)
