@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 #define PSSR_COMPUTE(TAPS)                                                                                        \
     {                                                                                                             \
+        __builtin_amdgcn_s_setprio(2);      /* the multiplying wave goes first: the other workgroup is staging */ \
         _Pragma("unroll") for (int t = 0; t < (TAPS); ++t) {                                                      \
             u32x4 af[C::MI], bf[C::NJ];                                                                           \
             _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
                 _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
         }                                                                                                         \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
     }
 
     // source 0 (TAPS0 taps) then the optional 1x1 source 1; the loads of the next chunk fly during the MFMAs
