@@ -479,16 +479,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             if (full_ || tid < (TAPS) * PT - it * 256) *(u32x4*)(Bs + tid * 16 + it * 4096) = b_reg[it];          \
         }                                                                                                         \
     }
+#define PSSR_FRAGS(T_, BUF)                                                                                       \
+    {                                                                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                      \
+            af[BUF][mi] = *(const u32x4*)(As + a_rd[mi][(TAPS_) == TAPS0 ? (T_) : CT]);                           \
+        _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[BUF][nj] = *(const u32x4*)(Bs + (T_) * BN * 32 + b_off[nj]); \
+    }
+    // the fragments of tap t + 1 are requested before the MFMAs of tap t (two register sets): left to itself hipcc keeps
+    // one or two reads of lookahead and every tap waits ~64 cycles for LDS
 #define PSSR_COMPUTE(TAPS)                                                                                        \
     {                                                                                                             \
+        constexpr int TAPS_ = (TAPS);                                                                             \
+        u32x4 af[2][C::MI], bf[2][C::NJ];                                                                         \
         __builtin_amdgcn_s_setprio(2);      /* the multiplying wave goes first: the other workgroup is staging */ \
-        _Pragma("unroll") for (int t = 0; t < (TAPS); ++t) {                                                      \
-            u32x4 af[C::MI], bf[C::NJ];                                                                           \
+        PSSR_FRAGS(0, 0)                                                                                          \
+        if (sizeof(T) == 2) __builtin_amdgcn_sched_group_barrier(0x100, C::MI + C::NJ, 0);                        \
+        _Pragma("unroll") for (int t = 0; t < TAPS_; ++t) {                                                       \
+            if (t + 1 < TAPS_) PSSR_FRAGS(t + 1, (t + 1) & 1)                                                     \
             _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                af[mi] = *(const u32x4*)(As + a_rd[mi][(TAPS) == TAPS0 ? t : CT]);                                \
-            _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]); \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);         \
+                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[t & 1][mi], bf[t & 1][nj]); \
+            if (sizeof(T) == 2) {           /* pin the order: the next tap's LDS reads, then this tap's MFMAs */     \
+                if (t + 1 < TAPS_) __builtin_amdgcn_sched_group_barrier(0x100, C::MI + C::NJ, 0);                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ, 0);                                    \
+            }                                                                                                     \
         }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     }
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #undef PSSR_ISSUE
 #undef PSSR_COMMIT
 #undef PSSR_COMPUTE
+#undef PSSR_FRAGS
 
     if (p.ksplit > 1) {
         // raw accumulators of this K slice: ws[((block * ksplit + slice) * 16*MI*NJ + j) * 256 + tid] as float4 (coalesced)
