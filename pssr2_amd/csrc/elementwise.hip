@@ -104,12 +104,40 @@ __global__ void nchw_stats_kernel(const float* __restrict__ x, int n, int c, lon
     }
 }
 
+// Sum of the f64 statistic stripes for one channel with the stripes spread over SG thread groups of the workgroup (these kernels
+// are a few microseconds of pure dependent latency on the step's critical path: 64 serial loads per thread otherwise).
+// Launch with dim3(STRIPE_CH, STRIPE_SG) threads; returns the full sums in every thread of group 0 (others return partials).
+constexpr int STRIPE_CH = 32, STRIPE_SG = 8;
+template <int NV>
+__device__ __forceinline__ void stripe_sums(const double* __restrict__ base, long stripe_stride, const long (&off)[NV], int stripes, bool active,
+                                            double (&out)[NV]) {
+    __shared__ double red[STRIPE_SG][STRIPE_CH][NV];
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    if (active)
+        for (int k = threadIdx.y; k < stripes; k += STRIPE_SG)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += base[(long)k * stripe_stride + off[v]];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[threadIdx.y][threadIdx.x][v] = acc[v];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double t = 0.0;
+        for (int g = 0; g < STRIPE_SG; ++g) t += red[g][threadIdx.x][v];
+        out[v] = t;
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
                                    float* rmean, float* rvar, float* scale, float* shift, float* mean, float* invstd, int c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < PSSR_STAT_STRIPES; ++k) { s1 += stats[(long)k * 2 * c + i]; s2 += stats[(long)k * 2 * c + c + i]; }
+    const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
+    const long off[2] = {i, (long)c + i};
+    double sv[2];
+    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_STRIPES, i < c, sv);
+    if (i >= c || threadIdx.y != 0) return;
+    const double s1 = sv[0], s2 = sv[1];
     const double mu = s1 / count;
     double var = s2 / count - mu * mu;
     if (var < 0) var = 0;
@@ -137,10 +165,12 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 
 __global__ void bn_bwd_coefs_kernel(const double* stats, double count, const float* gamma, const float* mean, const float* invstd,
                                     float* A, float* B, float* Cc, float* dgamma, float* dbeta, int c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < PSSR_STAT_STRIPES; ++k) { s1 += stats[(long)k * 2 * c + i]; s2 += stats[(long)k * 2 * c + c + i]; }
+    const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
+    const long off[2] = {i, (long)c + i};
+    double sv[2];
+    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_STRIPES, i < c, sv);
+    if (i >= c || threadIdx.y != 0) return;
+    const double s1 = sv[0], s2 = sv[1];
     const double c1 = s1 / count, c2 = s2 / count;
     const double g = gamma[i], is = invstd[i], mu = mean[i];
     A[i] = (float)(g * is);
@@ -375,10 +405,12 @@ __global__ void clip_u8_kernel(const float* __restrict__ in, uint8_t* __restrict
 }
 
 __global__ void f64_to_f32_kernel(const double* in, float* out, int n, int accumulate, int stripes) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int k = 0; k < stripes; ++k) s += in[(long)k * n + i];
+    const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
+    const long off[1] = {i};
+    double sv[1];
+    stripe_sums<1>(in, (long)n, off, stripes, i < n, sv);
+    if (i >= n || threadIdx.y != 0) return;
+    const double s = sv[0];
     out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
@@ -409,7 +441,7 @@ int pssr_bn_finalize(const double* stats, double count, const float* gamma, cons
                      float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, int c, pssr_stream_t s) {
     PSSR_CHECK(stats && scale && shift && c > 0 && count > 0, PSSR_ERR_ARG, "bn_finalize: bad args");
     PSSR_CHECK((running_mean == nullptr) == (running_var == nullptr), PSSR_ERR_ARG, "bn_finalize: running stats come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, (hipStream_t)s, stats, count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, STRIPE_CH)), dim3(STRIPE_CH, STRIPE_SG), 0, (hipStream_t)s, stats, count, gamma, beta, eps, momentum,
                        running_mean, running_var, scale, shift, mean, invstd, c);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
@@ -426,7 +458,7 @@ int pssr_bn_eval_affine(const float* gamma, const float* beta, const float* runn
 int pssr_bn_bwd_coefs(const double* stats, double count, const float* gamma, const float* mean, const float* invstd,
                       float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta, int c, pssr_stream_t s) {
     PSSR_CHECK(stats && gamma && mean && invstd && coef_a && coef_b && coef_c && c > 0 && count > 0, PSSR_ERR_ARG, "bn_bwd_coefs: bad args");
-    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, (hipStream_t)s, stats, count, gamma, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(cdiv(c, STRIPE_CH)), dim3(STRIPE_CH, STRIPE_SG), 0, (hipStream_t)s, stats, count, gamma, mean, invstd,
                        coef_a, coef_b, coef_c, dgamma, dbeta, c);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
@@ -548,7 +580,7 @@ int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t s) {
 
 int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, int stripes, pssr_stream_t s) {
     PSSR_CHECK(in && out && n > 0 && stripes > 0, PSSR_ERR_ARG, "f64_to_f32: bad args");
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)s, in, out, n, accumulate, stripes);
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, STRIPE_CH)), dim3(STRIPE_CH, STRIPE_SG), 0, (hipStream_t)s, in, out, n, accumulate, stripes);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
