@@ -202,6 +202,41 @@ def main():
 
     graphs = {}
 
+    def capture_split(eng):
+        """fwd + loss + first part of the backward | rest of the backward, as two hipGraphs sharing one memory pool.  The engine's
+        backward is driven directly (d loss / d output from autograd.grad) so that the capture switches graphs on this thread."""
+        def body(cb):
+            opt.zero_grad()
+            hr, lr = next_batch()
+            hr_hat = model(lr)
+            loss = loss_fn(hr_hat / 255, hr / 255)
+            (dout,) = torch.autograd.grad(loss * loss_scale if loss_scale != 1.0 else loss, hr_hat)
+            eng.backward(dout, split_cb=cb)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body(lambda: None)
+                if world > 1:
+                    torch.distributed.all_reduce(eng._flat_grad)     # a real data-parallel step: the ranks must stay identical
+                opt.step(grad_scale=1.0 / (loss_scale * world))      # the weights must be stale at capture time so that the
+        torch.cuda.current_stream().wait_stream(side)                # forward's re-pack of every conv weight is part of the graph
+        torch.cuda.synchronize()
+        stale = [c for c in eng._convs.values() for key in c.packed if c.version.get(key) != c.m.weight._version]
+        if not stale:
+            raise RuntimeError("weights not stale before capture: the packed-weight refresh would be missing from the graph")
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            g1.capture_begin(pool=pool)
+            body(lambda: (g1.capture_end(), g2.capture_begin(pool=pool)))
+            g2.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        return g1, g2, eng.grad_split_offset()
+
     def capture(name, body):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -234,15 +269,41 @@ def main():
             def fwd_bwd_fresh():
                 opt.zero_grad()               # Python-only (sets .grad = None): the engine then publishes views of its flat buffer
                 fwd_bwd()
-            capture("fwd_bwd", fwd_bwd_fresh)
+            eng = model._engine
+            split = None
+            if args.model == "resunet" and os.environ.get("PSSR_BENCH_OVERLAP", "1") != "0":
+                # Two graphs split where ~85 % of the gradient bytes (reconstruction, decoder, deepest encoder block) are final: their
+                # all-reduce is launched between the two replays and runs on RCCL's stream under the rest of the backward pass.
+                try:
+                    split = capture_split(eng)
+                except Exception as e:                       # any capture problem: the single-graph path below
+                    if rank == 0:
+                        print(f"[bench] split capture unavailable ({type(e).__name__}: {e}); all-reduce after the backward graph", file=sys.stderr)
+                    split = None
+                    torch.cuda.synchronize()
+            if split is None:
+                capture("fwd_bwd", fwd_bwd_fresh)
             # Replays run no Python, so the .grad views published during capture must stay in place: no zero_grad()
             # between steps (the captured backward zeroes the flat buffer itself), and FusedAdamW consumes the flat
             # buffer the all-reduce just averaged.
-            assert all(p.grad is not None and p.grad._base is model._engine._flat_grad for p in model.parameters())
+            assert all(p.grad is not None and p.grad._base is eng._flat_grad for p in model.parameters())
 
-            def fn(s):
-                graphs["fwd_bwd"].replay()
-                reduce_and_update(zero=False)
+            if split is not None:
+                g1, g2, a0 = split
+                flat = eng._flat_grad
+
+                def fn(s):
+                    g1.replay()
+                    h1 = torch.distributed.all_reduce(flat[a0:], async_op=True) if world > 1 else None    # waits for g1 on RCCL's stream, runs under g2
+                    g2.replay()
+                    if world > 1:
+                        h2 = torch.distributed.all_reduce(flat[:a0], async_op=True)
+                        h1.wait(), h2.wait()
+                    opt.step(grad_scale=1.0 / (loss_scale * world))
+            else:
+                def fn(s):
+                    graphs["fwd_bwd"].replay()
+                    reduce_and_update(zero=False)
         else:
             if world > 1:
                 model._engine.attach_reducer()
@@ -311,6 +372,9 @@ def main():
         timer.remove()
         measured_in = ("instrumented eager pass after the timed region, kernels one at a time on the launch stream (the timed region replays "
                        "the same kernels from a hipGraph, with the weight-gradient kernels overlapping on a second stream)")
+    if os.environ.get("PSSR_BENCH_CHECKSUM") == "1":        # rehearsal aid: compare launch structures by their effect on the weights
+        cs = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        print(f"[bench] rank {rank} param checksum {cs:.6f}", file=sys.stderr)
     if rank == 0:
         conv = timer.summary()
         per_step = sheet_tiles if args.mode == "sheet" else args.batch

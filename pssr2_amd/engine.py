@@ -172,6 +172,12 @@ class Engine:
                     prm.grad.add_(view)
         return {}
 
+    def grad_split_offset(self):
+        """First element of the flat gradient buffer that is final when ``backward(split_cb=...)`` calls back: the deepest
+        encoder block's first parameter (parameters are laid out in module order: norm, encoder.0.., decoder.., reconstruction)."""
+        first = next(self.model.encoder[self.L - 1].parameters())
+        return self._goffs[self._gindex[id(first)]]
+
     def _gbuf(self, param):
         """Zeroed gradient slot of a parameter (a view of the flat buffer)."""
         return self._gviews[self._gindex[id(param)]]
@@ -615,7 +621,10 @@ class Engine:
         ops.conv2d(dy, blk.c, c0, dsrc, dsrc_c, n=n, h=hh, w=ww, x1=dz, cin1=blk.c, w1=c1)
         self._ready(grads, list(module.parameters()))
 
-    def backward(self, dout):
+    def backward(self, dout, split_cb=None):
+        """``split_cb`` (optional) is called once, when the gradients of Reconstruction, the decoder and the deepest encoder
+        block are final in the flat buffer (everything from ``grad_split_offset()`` on: ~85 % of a default ResUNet's bytes) and
+        the side stream is joined: a data-parallel driver launches their all-reduce there, under the rest of the backward."""
         if self.saved is None:
             raise RuntimeError("backward called without a training-mode forward (or called twice)")
         p, x = self.saved
@@ -653,6 +662,9 @@ class Engine:
             else:
                 src, cin, dsrc, dsrc_c = p.pooled[i - 1], ops.pad_to(hid[i - 1], 16), bw.dpooled[i - 1], hid[i - 1]
             self._block_backward(p, bw, grads, blk, m.encoder[i], src, cin, i == 0, out_buf, out_off, bw.dout[i], dsrc, dsrc_c)
+            if split_cb is not None and i == Lv - 1 and Lv > 1:
+                self._side_join()
+                split_cb()
         # ---- input BatchNorm parameters
         st = p.bn_in
         st.bstats.zero_()

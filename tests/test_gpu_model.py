@@ -244,3 +244,34 @@ def test_fp16_three_channel_vs_oracle():
     before = [p.detach().clone() for p in model.parameters()]
     assert scaler.step(opt, list(model.parameters())) is False and scaler.scale_value == s0 / 2
     assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+
+
+def test_backward_split_point_gradients_are_final():
+    """Engine.backward(split_cb=...) (the hook a data-parallel driver uses to start the all-reduce of the big gradients under the
+    rest of the backward pass): at the callback everything from grad_split_offset() on is final -- no later kernel, on either
+    stream, touches it -- and the remainder is not yet."""
+    from pssr2_amd.models import ResUNet
+    torch.manual_seed(3)
+    model = ResUNet(hidden=[16, 32, 64]).cuda()
+    model.compute_dtype = torch.bfloat16
+    model.train()
+    x = (torch.rand(4, 1, 64, 64) * 255).cuda()
+    y = model(x)
+    dout = torch.randn_like(y) * 1e-3
+    eng = model._engine
+    snap = {}
+
+    def cb():
+        torch.cuda.synchronize()
+        a0 = eng.grad_split_offset()
+        snap["a0"], snap["tail"], snap["head"] = a0, eng._flat_grad[a0:].clone(), eng._flat_grad[:a0].clone()
+
+    eng.backward(dout, split_cb=cb)
+    torch.cuda.synchronize()
+    a0 = snap["a0"]
+    names = [n for n, _ in model.named_parameters()]
+    first_tail = names[[eng._goffs[i] for i in range(len(names))].index(a0)]
+    assert first_tail.startswith("encoder.2.")                                   # deepest encoder block of a 3-level net
+    assert torch.equal(eng._flat_grad[a0:], snap["tail"]) and float(snap["tail"].abs().sum()) > 0
+    assert not torch.equal(eng._flat_grad[:a0], snap["head"])                     # encoder.0/1 and norm came after the callback
+    assert all(p.grad is not None and p.grad._base is eng._flat_grad for p in model.parameters())
