@@ -271,7 +271,7 @@ def main():
                 fwd_bwd()
             eng = model._engine
             split = None
-            if args.model == "resunet" and os.environ.get("PSSR_BENCH_OVERLAP", "1") != "0":
+            if os.environ.get("PSSR_BENCH_OVERLAP", "1") != "0":
                 # Two graphs split where ~85 % of the gradient bytes (reconstruction, decoder, deepest encoder block) are final: their
                 # all-reduce is launched between the two replays and runs on RCCL's stream under the rest of the backward pass.
                 try:

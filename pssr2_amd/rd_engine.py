@@ -408,7 +408,13 @@ class RDEngine(Engine):
         ops.dwconv7(sc.ddw, bk.wpf, None, G, n, st.h, st.w, bk.c_in, code, out_coff=gcoff, accumulate=True)
         self._ready(grads, list(bk.mod.parameters()))
 
-    def backward(self, dout):
+    def grad_split_offset(self):
+        """First element of the flat gradient buffer that is final at the split callback of ``backward``: the decoder's first
+        parameter (module order: norm, encoder, decoder, reconstruction; the backward runs reconstruction, decoder, encoder)."""
+        first = next(self.model.decoder.parameters())
+        return self._goffs[self._gindex[id(first)]]
+
+    def backward(self, dout, split_cb=None):
         if self.saved is None:
             raise RuntimeError("backward called without a training-mode forward (or called twice)")
         p, x = self.saved
@@ -431,6 +437,9 @@ class RDEngine(Engine):
                 ops.pixel_shuffle(bw.dout[k], bw.dfeat, n, *p.dims[k], h0, rr, code, inverse=True)
             self._block_backward(p, bw, grads, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, bw.dout[k], bw.dcat[k],
                                  p.shuf_c[k] + m.skips[k])
+        if split_cb is not None:       # reconstruction + decoder gradients (the tail of the flat buffer) are final
+            self._side_join()
+            split_cb()
         # ---- encoder, last stage first
         bw.small.buf.zero_()
         for i in range(len(p.stages) - 1, -1, -1):

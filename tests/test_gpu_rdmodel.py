@@ -180,3 +180,32 @@ def test_default_model_vs_oracle_eval():
     assert abs(_psnr(y, hr) - _psnr(ref, hr)) <= 1e-3
     with pytest.raises(RuntimeError, match="MI355X"):
         model(x)
+
+
+@pytest.mark.gpu
+def test_rd_backward_split_point_gradients_are_final():
+    """RDEngine.backward(split_cb=...): reconstruction + decoder gradients (the tail of the flat buffer) are final at the callback."""
+    from pssr2_amd.models import RDResUNet
+    torch.manual_seed(5)
+    model = RDResUNet(channels=1).cuda()
+    model.compute_dtype = torch.bfloat16
+    model.train()
+    x = (torch.rand(2, 1, 64, 64) * 255).cuda()
+    y = model(x)
+    eng = model._engine
+    snap = {}
+
+    def cb():
+        torch.cuda.synchronize()
+        a0 = eng.grad_split_offset()
+        snap["a0"], snap["tail"], snap["head"] = a0, eng._flat_grad[a0:].clone(), eng._flat_grad[:a0].clone()
+
+    eng.backward(torch.randn_like(y) * 1e-3, split_cb=cb)
+    torch.cuda.synchronize()
+    a0 = snap["a0"]
+    assert 0 < a0 < eng._flat_grad.numel()
+    assert torch.equal(eng._flat_grad[a0:], snap["tail"]) and float(snap["tail"].abs().sum()) > 0
+    assert not torch.equal(eng._flat_grad[:a0], snap["head"])
+    frac = 1.0 - a0 / eng._flat_grad.numel()
+    assert frac > 0.3, frac              # a substantial share of the bytes can be reduced under the encoder's backward
+    print("tail fraction", frac)
