@@ -178,11 +178,12 @@ __global__ __launch_bounds__(256) void dwconv7_seg_kernel(Ref in, const float* _
             const int sy = y + ky - 3;
             if (sy < 0 || sy >= h) continue;
             float v[14][4];
-            const long row = img_base + (long)sy * w;
+            const T* xrow = at<T>(in, img_base + (long)sy * w + xs, c0);      // one base per row, constant strides, edge padding only
+            const bool left = xs == 0, right = xs + 8 == w;
 #pragma unroll
             for (int j = 0; j < 14; ++j) {
-                const int sx = xs - 3 + j;
-                if (sx >= 0 && sx < w) load4(at<T>(in, row + sx, c0), v[j]);
+                const bool pad = (j < 3 && left) || (j >= 11 && right);
+                if (!pad) load4(xrow + (long)(j - 3) * in.cs, v[j]);
                 else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
             }
 #pragma unroll
@@ -299,12 +300,17 @@ __global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, 
         const int sy = y + ky - 3;
         if (sy < 0 || sy >= h) continue;
         float g[8][4], v[14][4];
+        // one base address per row segment, constant strides from it; only the first / last segment of a row needs the
+        // left / right zero padding (the per-load 64-bit index arithmetic and range tests were most of this kernel's VALU work)
+        const T* grow = at<T>(dy, img_base + (long)y * w + xs, cg * 4);
+        const T* xrow = at<T>(x, img_base + (long)sy * w + xs, cg * 4);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) load4(at<T>(dy, img_base + (long)y * w + xs + o, cg * 4), g[o]);
+        for (int o = 0; o < 8; ++o) load4(grow + (long)o * dy.cs, g[o]);
+        const bool left = xs == 0, right = xs + 8 == w;
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
-            const int sx = xs - 3 + j;
-            if (sx >= 0 && sx < w) load4(at<T>(x, img_base + (long)sy * w + sx, cg * 4), v[j]);
+            const bool pad = (j < 3 && left) || (j >= 11 && right);
+            if (!pad) load4(xrow + (long)(j - 3) * x.cs, v[j]);
             else { v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f; }
         }
 #pragma unroll
