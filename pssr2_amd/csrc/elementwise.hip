@@ -372,6 +372,71 @@ __global__ void bn_bwd_apply_kernel(Ref g, Ref y, const float* A, const float* B
     }
 }
 
+// 16-bit storage, power-of-two channel counts (every BatchNorm of the models): 8 channels = one 16-byte access per thread and
+// tensor, the thread's channels fixed for the whole launch (the grid stride is a multiple of the channel-group count), so the
+// per-channel coefficients / statistics live in registers and the loop body is loads, a few FMAs and a store.
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply8_kernel(Ref g, Ref y, const float* __restrict__ A, const float* __restrict__ B,
+                                                            const float* __restrict__ Cc, MRef dy, long npix, int c, int cg_log2) {
+    using X = TT<T>;
+    const int cg = 1 << cg_log2;
+    const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c0 = (int)(t0 & (cg - 1)) * 8;
+    float a[8], b[8], cc[8];
+    load4(A + c0, a); load4(A + c0 + 4, a + 4); load4(B + c0, b); load4(B + c0 + 4, b + 4); load4(Cc + c0, cc); load4(Cc + c0 + 4, cc + 4);
+    const long total = npix << cg_log2;
+    for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i >> cg_log2;
+        float gv[8], yv[8], o[8];
+        X::unpack(*(const u32x4*)at<T>(g, pix, c0), gv);
+        X::unpack(*(const u32x4*)at<T>(y, pix, c0), yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(a[e], gv[e], fmaf(b[e], yv[e], cc[e]));
+        *(u32x4*)at<T>(dy, pix, c0) = X::pack(o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void relu_bwd_stats8_kernel(Ref dout, Ref out, Ref y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              MRef dz, double* __restrict__ stats, long npix, int c, int cg_log2) {
+    using X = TT<T>;
+    __shared__ float lds[TPB * 16];
+    const int cg = 1 << cg_log2;
+    const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int cgi = (int)(t0 & (cg - 1)), c0 = cgi * 8;
+    float mu[8], is[8], s1[8], s2[8];
+    load4(mean + c0, mu); load4(mean + c0 + 4, mu + 4); load4(invstd + c0, is); load4(invstd + c0 + 4, is + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const long total = npix << cg_log2;
+    for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i >> cg_log2;
+        float gv[8], ov[8], yv[8];
+        X::unpack(*(const u32x4*)at<T>(dout, pix, c0), gv);
+        X::unpack(*(const u32x4*)at<T>(out, pix, c0), ov);
+        X::unpack(*(const u32x4*)at<T>(y, pix, c0), yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gv[e] = ov[e] > 0.f ? gv[e] : 0.f;
+            s1[e] += gv[e];
+            s2[e] += gv[e] * (yv[e] - mu[e]) * is[e];
+        }
+        *(u32x4*)at<T>(dz, pix, c0) = X::pack(gv);
+    }
+    // threads tid, tid + cg, ... of the workgroup hold the same channels (TPB is a multiple of cg): combine, then f64 atomics
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lds[tid * 16 + e] = s1[e]; lds[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    double* dst = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+    for (int j = tid; j < cg * 16; j += TPB) {
+        const int g_ = j >> 4, q = j & 15;
+        float t = 0.f;
+        for (int k = g_; k < TPB; k += cg) t += lds[k * 16 + q];
+        atomicAdd(dst + (long)(q >> 3) * c + g_ * 8 + (q & 7), (double)t);
+    }
+}
+
 template <typename T>
 __global__ void channel_sum_kernel(Ref x, double* out, long npix, int c, ChanMap m) {
     __shared__ float lds[TPB * 4];
@@ -537,6 +602,20 @@ int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out,
     PSSR_CHECK(dout && out && y && mean && invstd && dz && stats && npix > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "relu_bwd_stats: bad args");
     CHECK_REF("relu_bwd_stats dout", do_cs, do_co, c); CHECK_REF("relu_bwd_stats out", o_cs, o_co, c);
     CHECK_REF("relu_bwd_stats y", y_cs, y_co, c); CHECK_REF("relu_bwd_stats dz", dz_cs, dz_co, c);
+    if (dtype != PSSR_F32 && c >= 8 && c <= 8 * TPB && (c & (c - 1)) == 0 && ((do_cs | do_co | o_cs | o_co | y_cs | y_co | dz_cs | dz_co) & 7) == 0) {
+        int lg = 0;
+        while ((8 << lg) < c) ++lg;
+        const long threads = npix << lg;
+        const int grid = (int)((threads + TPB - 1) / TPB < 2048 ? (threads + TPB - 1) / TPB : 2048);
+        if (dtype == PSSR_BF16)
+            hipLaunchKernelGGL(relu_bwd_stats8_kernel<bf16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dout, do_cs, do_co}, Ref{out, o_cs, o_co},
+                               Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, (long)npix, c, lg);
+        else
+            hipLaunchKernelGGL(relu_bwd_stats8_kernel<f16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dout, do_cs, do_co}, Ref{out, o_cs, o_co},
+                               Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, (long)npix, c, lg);
+        PSSR_LAUNCH_CHECK();
+        return PSSR_OK;
+    }
     const ChanMap m = make_map(c);
     DISPATCH_T(dtype, hipLaunchKernelGGL(relu_bwd_stats_kernel<T>, dim3(grid_for(npix, m)), dim3(TPB), 0, (hipStream_t)s, Ref{dout, do_cs, do_co},
                                          Ref{out, o_cs, o_co}, Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, (long)npix, c, m));
@@ -548,6 +627,20 @@ int pssr_bn_bwd_apply(const void* g, int g_cs, int g_co, const void* y, int y_cs
                       const float* coef_c, void* dy, int dy_cs, int dy_co, int64_t npix, int c, int dtype, pssr_stream_t s) {
     PSSR_CHECK(g && y && coef_a && coef_b && coef_c && dy && npix > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "bn_bwd_apply: bad args");
     CHECK_REF("bn_bwd_apply g", g_cs, g_co, c); CHECK_REF("bn_bwd_apply y", y_cs, y_co, c); CHECK_REF("bn_bwd_apply dy", dy_cs, dy_co, c);
+    if (dtype != PSSR_F32 && c >= 8 && c <= 8 * TPB && (c & (c - 1)) == 0 && ((g_cs | g_co | y_cs | y_co | dy_cs | dy_co) & 7) == 0) {
+        int lg = 0;
+        while ((8 << lg) < c) ++lg;
+        const long threads = (long)npix << lg;
+        const int grid = (int)((threads + TPB - 1) / TPB < 4096 ? (threads + TPB - 1) / TPB : 4096);
+        if (dtype == PSSR_BF16)
+            hipLaunchKernelGGL(bn_bwd_apply8_kernel<bf16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, Ref{y, y_cs, y_co}, coef_a, coef_b,
+                               coef_c, MRef{dy, dy_cs, dy_co}, (long)npix, c, lg);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply8_kernel<f16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, Ref{y, y_cs, y_co}, coef_a, coef_b,
+                               coef_c, MRef{dy, dy_cs, dy_co}, (long)npix, c, lg);
+        PSSR_LAUNCH_CHECK();
+        return PSSR_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid1d(npix * (c / 4))), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co},
                                          Ref{y, y_cs, y_co}, coef_a, coef_b, coef_c, MRef{dy, dy_cs, dy_co}, (long)npix, c));
     PSSR_LAUNCH_CHECK();
