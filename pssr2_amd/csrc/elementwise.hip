@@ -330,6 +330,49 @@ __global__ void pixel_shuffle_kernel(Ref lo, MRef hi, int n, int h, int w, int c
     }
 }
 
+// r = 2, 16-bit storage, channel counts / strides / offsets multiples of 8: a thread moves the 32 low-resolution channels
+// 4c + k (c = 0..7 of its group, k = 2i + j) = 64 contiguous bytes <-> the same 8 high-resolution channels of the 4 pixels
+// (2y + i, 2x + j), 16 bytes each, de-interleaving 16-bit halves in registers (the kernel above moves 2 bytes per thread).
+template <typename T>
+__global__ __launch_bounds__(TPB) void pixel_shuffle2_kernel(Ref lo, MRef hi, int n, int h, int w, int c_hi, int inverse) {
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    const int cg = c_hi / 8;
+    const long total = (long)n * h * w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long pix = i / cg;
+        const int x = (int)(pix % w); pix /= w;
+        const int y = (int)(pix % h);
+        const long img = pix / h;
+        const long plo = (img * h + y) * w + x;
+        unsigned short* lop = (unsigned short*)lo.p + plo * lo.cs + lo.co + g * 32;
+        unsigned short e[32];
+        if (!inverse) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(u32x4*)(e + 8 * q) = *(const u32x4*)(lop + 8 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long phi = (img * 2 * h + 2 * y + (k >> 1)) * (2L * w) + 2 * x + (k & 1);
+            unsigned short* hip_ = (unsigned short*)hi.p + phi * hi.cs + hi.co + g * 8;
+            unsigned short v[8];
+            if (!inverse) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = e[4 * c + k];
+                *(u32x4*)hip_ = *(const u32x4*)v;
+            } else {
+                *(u32x4*)v = *(const u32x4*)hip_;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) e[4 * c + k] = v[c];
+            }
+        }
+        if (inverse) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(u32x4*)(lop + 8 * q) = *(const u32x4*)(e + 8 * q);
+        }
+    }
+}
+
 template <typename T>
 __global__ void relu_bwd_stats_kernel(Ref dout, Ref out, Ref y, const float* mean, const float* invstd, MRef dz, double* stats,
                                       long npix, int c, ChanMap m) {
@@ -590,6 +633,13 @@ int pssr_pixel_shuffle(const void* lo, int lo_cs, int lo_co, void* hi, int hi_cs
     PSSR_CHECK(lo && hi && n > 0 && h > 0 && w > 0 && c_hi > 0 && r > 0, PSSR_ERR_ARG, "pixel_shuffle: bad args");
     PSSR_CHECK(lo_co + c_hi * r * r <= lo_cs && hi_co + c_hi <= hi_cs, PSSR_ERR_ARG, "pixel_shuffle: slice exceeds stride");
     const long total = (long)n * h * r * w * r * c_hi;
+    if (r == 2 && dtype != PSSR_F32 && c_hi % 8 == 0 && ((lo_cs | lo_co | hi_cs | hi_co) & 7) == 0) {
+        const long threads = (long)n * h * w * (c_hi / 8);
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<bf16_t>, dim3(grid1d(threads)), dim3(TPB), 0, (hipStream_t)s, Ref{lo, lo_cs, lo_co},
+                           MRef{hi, hi_cs, hi_co}, n, h, w, c_hi, inverse);      // a byte permutation: one build serves bf16 and fp16
+        PSSR_LAUNCH_CHECK();
+        return PSSR_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(pixel_shuffle_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, Ref{lo, lo_cs, lo_co},
                                          MRef{hi, hi_cs, hi_co}, n, h, w, c_hi, r, inverse));
     PSSR_LAUNCH_CHECK();

@@ -1,0 +1,58 @@
+"""Element-wise / layout kernels with vectorised fast paths (csrc/elementwise.hip) vs torch on the CPU: bit-exact data movement,
+statistics within f32 summation noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [(2, 6, 10, 16, 2, 8, 16), (1, 4, 4, 8, 2, 0, 0), (2, 3, 5, 4, 4, 0, 8), (1, 8, 8, 12, 2, 4, 0)])
+def test_pixel_shuffle_and_inverse(case, dt):
+    """F.pixel_shuffle(x, r) into a channel slice of a wider NHWC buffer and back (resunet.py:82-84): r = 2 with 8-aligned slices
+    takes the 16-byte kernel, everything else the generic one; both are pure permutations (bit-exact)."""
+    from pssr2_amd import ops
+    n, h, w, c_hi, r, lo_off, hi_off = case
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, c_hi * r * r, h, w, generator=g).to(dt)
+    want = F.pixel_shuffle(x.float(), r).to(dt)                              # [n, c_hi, h*r, w*r]
+    lo = torch.zeros(n, h, w, lo_off + c_hi * r * r + 8, dtype=dt, device="cuda")
+    lo[..., lo_off:lo_off + c_hi * r * r] = x.permute(0, 2, 3, 1).cuda()
+    hi = torch.full((n, h * r, w * r, hi_off + c_hi + 8), 7.0, dtype=dt, device="cuda")
+    ops.pixel_shuffle(lo, hi, n, h, w, c_hi, r, code, lo_coff=lo_off, hi_coff=hi_off)
+    got = hi[..., hi_off:hi_off + c_hi].permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got, want)
+    assert torch.all(hi[..., :hi_off] == 7.0) and torch.all(hi[..., hi_off + c_hi:] == 7.0)      # neighbours untouched
+    back = torch.full_like(lo, 3.0)
+    ops.pixel_shuffle(back, hi, n, h, w, c_hi, r, code, lo_coff=lo_off, hi_coff=hi_off, inverse=True)
+    assert torch.equal(back[..., lo_off:lo_off + c_hi * r * r], lo[..., lo_off:lo_off + c_hi * r * r])
+    assert torch.all(back[..., :lo_off] == 3.0)
+
+
+@pytest.mark.parametrize("c", [64, 24, 256])
+def test_bn_backward_elementwise_kernels(c):
+    """relu_bwd_stats + bn_bwd_apply (the BatchNorm / ReLU backward of a ResBlock tail, _blocks.py:39-41): power-of-two channel
+    counts take the 8-channel kernels, c = 24 the generic ones."""
+    from pssr2_amd import ops
+    dt, code = torch.bfloat16, ops.dtype_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(c)
+    npix = 3 * 20 * 12
+    dout, out, y = (torch.randn(npix, c, generator=g).to(dt) for _ in range(3))
+    mean, invstd = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dz = torch.empty(npix, c, dtype=dt, device="cuda")
+    stats = torch.zeros(ops.STAT_STRIPES * 2 * c, dtype=torch.float64, device="cuda")
+    ops.relu_bwd_stats(dout.cuda(), out.cuda(), y.cuda(), mean.cuda(), invstd.cuda(), dz, stats, npix, c, code)
+    want_dz = torch.where(out.float() > 0, dout.float(), torch.zeros(())).to(dt)
+    assert torch.equal(dz.cpu(), want_dz)
+    st = stats.view(ops.STAT_STRIPES, 2, c).sum(0).cpu()
+    gz = want_dz.double()
+    np.testing.assert_allclose(st[0].numpy(), gz.sum(0).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (gz * (y.double() - mean.double()) * invstd.double()).sum(0).numpy(), rtol=1e-4, atol=2e-2)
+    a, b, cc = (torch.randn(c, generator=g) for _ in range(3))
+    dy = torch.empty(npix, c, dtype=dt, device="cuda")
+    ops.bn_bwd_apply(dz, y.cuda(), a.cuda(), b.cuda(), cc.cuda(), dy, npix, c, code)
+    want = torch.addcmul(torch.addcmul(cc, b, y.float()), a, want_dz.float())          # a*g + (b*y + c), as the kernel's fma order
+    assert (dy.cpu().float() - want).abs().max() <= 2.0 ** -7 * want.abs().max()
