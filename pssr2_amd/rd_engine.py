@@ -31,7 +31,40 @@ def _obj(**kw):
     return o
 
 
+
+class _ZeroArena:
+    """Zero-initialised scratch for one backward pass from ONE fill: the statistic / bias-sum buffers of every block are
+    consecutive slices of one tensor (the per-use ``zero_()`` launches were ~100 five-microsecond kernels per step).  The first
+    pass measures the need and serves its requests with individual fills."""
+
+    def __init__(self, dtype):
+        self.dtype, self.buf, self.need, self.pos, self.asked = dtype, None, 0, 0, 0
+
+    def begin(self, device):
+        if self.need and (self.buf is None or self.buf.numel() < self.need):
+            self.buf = torch.zeros(self.need, dtype=self.dtype, device=device)
+        elif self.buf is not None:
+            self.buf.zero_()
+        self.pos = self.asked = 0
+
+    def take(self, n, fallback):
+        """n zeroed elements: a slice of the arena, or (first pass / grown need) ``fallback`` zeroed in place."""
+        n_al = (n + 3) // 4 * 4
+        self.asked += n_al
+        self.need = max(self.need, self.asked)
+        if self.buf is not None and self.pos + n_al <= self.buf.numel():
+            out = self.buf[self.pos:self.pos + n]
+            self.pos += n_al
+            return out
+        fb = fallback[:n]
+        fb.zero_()
+        return fb
+
+
 class RDEngine(Engine):
+    _z64 = None
+    _z32 = None
+
     # ------------------------------------------------------------------ static structure
     def _structure(self, device):
         m = self.model
@@ -243,20 +276,19 @@ class RDEngine(Engine):
             c.specs[name] = spec
         return c.get(name, code)
 
-    def _ln_grads(self, bw, grads, ln_module, c):
+    def _ln_grads(self, bw, grads, ln_module, c, s64):
         iw, ib = self._gindex[id(ln_module.weight)], self._gindex[id(ln_module.bias)]
         if self._goffs[ib] == self._goffs[iw] + c:
             # weight and bias slots are adjacent in the flat gradient buffer: convert straight into them (no side copy)
             gb = self._flat_grad[self._goffs[iw]:self._goffs[iw] + 2 * c]
         else:
             gb = torch.empty(2 * c, dtype=torch.float32, device=bw.stat_ln.device)
-        ops.f64_to_f32(bw.stat_ln[:ops.STAT_STRIPES * 2 * c], gb)
+        ops.f64_to_f32(s64, gb)
         grads[id(ln_module.weight)], grads[id(ln_module.bias)] = gb[:c], gb[c:]
 
     def _bias_grad(self, bw, grads, bias, t, npix, c, code, coff=0):
         """d bias = per-channel sum of the output gradient (f64 striped accumulation)."""
-        s64 = bw.stat_ln[:ops.STAT_STRIPES * c]
-        s64.zero_()
+        s64 = self._z64.take(ops.STAT_STRIPES * c, bw.stat_ln)
         ops.channel_sum_nhwc(t, npix, c, s64, code, coff=coff)
         g = self._gbuf(bias)               # straight into the parameter's slot of the flat gradient buffer
         ops.f64_to_f32(s64, g)
@@ -355,27 +387,26 @@ class RDEngine(Engine):
         dwc, ln, c1, c2 = lay[0], lay[1], lay[2], lay[4]
         g = st.g
         # ---- layer scale (+ ESE gate): dt, dgamma (, d fc)
-        sc.A.zero_()
-        ops.image_channel_dot(G, bk.t, n, hw, g, 1.0, sc.A, code, a_coff=gcoff + bk.off)
+        A = self._z32.take(n * g, sc.A.view(-1)).view(n, g)
+        ops.image_channel_dot(G, bk.t, n, hw, g, 1.0, A, code, a_coff=gcoff + bk.off)
         dgam = self._gbuf(bk.mod.gamma)
         if st.ese:
             fc = lay[5].fc
             dbfc = self._gbuf(fc.bias)
             dwfc = self._gbuf(fc.weight)
-            ops.ese_bwd(sc.A, bk.gate, bk.u, bk.mod.gamma, bk.s_mean, fc.weight, hw, sc.du, dgam, dbfc, dwfc, sc.add)
+            ops.ese_bwd(A, bk.gate, bk.u, bk.mod.gamma, bk.s_mean, fc.weight, hw, sc.du, dgam, dbfc, dwfc, sc.add)
             grads[id(fc.weight)], grads[id(fc.bias)] = dwfc, dbfc
             self._before_write(sc.dt)
             ops.scale_nc(G, bk.gate, bk.mod.gamma, sc.add, sc.dt, n, hw, g, code, t_coff=gcoff + bk.off)
         else:
-            ops.ese_bwd(sc.A, None, None, bk.mod.gamma, None, None, hw, None, dgam, None, None, None)
+            ops.ese_bwd(A, None, None, bk.mod.gamma, None, None, hw, None, dgam, None, None, None)
             self._before_write(sc.dt)
             ops.scale_nc(G, None, bk.mod.gamma, None, sc.dt, n, hw, g, code, t_coff=gcoff + bk.off)
         grads[id(bk.mod.gamma)] = dgam
         # ---- second 1x1 conv (input = gelu(z))
         self._bias_grad(bw, grads, c2.bias, sc.dt, st.npix, g, code)
         self._wgrad1x1(p, grads, c2, sc.dt, g, 0, bk.z, bk.inter, st.h, st.w, gelu_in=True)
-        s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * bk.inter]
-        s64.zero_()
+        s64 = self._z64.take(ops.STAT_STRIPES * 2 * bk.inter, bw.stat_ln)
         self._before_write(sc.dz)
         ops.conv2d(sc.dt, sc.dt.shape[-1], self._pw(c2, "dgrad", code, mode=1), sc.dz, bk.inter, n=n, h=st.h, w=st.w,
                    epilogue=L.EPI_DGRAD_GELU, flags=L.FLAG_STATS, aux=bk.z, stats=s64)
@@ -387,11 +418,10 @@ class RDEngine(Engine):
         self._wgrad1x1(p, grads, c1, sc.dz, bk.inter, 0, bk.ln, cpad, st.h, st.w)
         ops.conv2d(sc.dz, bk.inter, self._pw(c1, "dgrad", code, mode=1), sc.dln, bk.c_in, n=n, h=st.h, w=st.w)
         # ---- LayerNorm2d
-        s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * bk.c_in]
-        s64.zero_()
+        s64 = self._z64.take(ops.STAT_STRIPES * 2 * bk.c_in, bw.stat_ln)
         self._before_write(sc.ddw)
         ops.layernorm2d_bwd(sc.dln, bk.dw, ln.weight, bk.stat[0], bk.stat[1], sc.ddw, s64, n, st.h, st.w, bk.c_in, code, c_pad=bk.c_in)
-        self._ln_grads(bw, grads, ln, bk.c_in)
+        self._ln_grads(bw, grads, ln, bk.c_in, s64)
         # ---- depthwise 7x7
         self._bias_grad(bw, grads, dwc.bias, sc.ddw, st.npix, bk.c_in, code)
         dww = self._gbuf(dwc.weight)
@@ -415,6 +445,8 @@ class RDEngine(Engine):
         return self._goffs[self._gindex[id(first)]]
 
     def backward(self, dout, split_cb=None):
+        if self._z64 is None:
+            self._z64, self._z32 = _ZeroArena(torch.float64), _ZeroArena(torch.float32)
         if self.saved is None:
             raise RuntimeError("backward called without a training-mode forward (or called twice)")
         p, x = self.saved
@@ -426,6 +458,8 @@ class RDEngine(Engine):
         hid, nd, r, h0 = self.hidden, len(self.hidden), self.r, self.h0
         grads = {}
         self._begin_backward(dev)
+        for arena in (self._z64, self._z32):
+            arena.begin(dev)
         self._head_backward(p, bw, grads, dout, p.feat, bw.dfeat)
         # ---- decoder, last block first
         for k in range(nd - 1, -1, -1):
@@ -459,22 +493,20 @@ class RDEngine(Engine):
                 ops.conv2d(G, ops.pad_to(st.c_in, 16), self._pw(conv, "dgrad", code, mode=5 if st.ds else 1), sc.dtr, kc,
                            n=n, h=st.h, w=st.w, in0_coff=gcoff)
                 Gp, gpo = bw.G[i - 1]
-                s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * st.tc]
-                s64.zero_()
+                s64 = self._z64.take(ops.STAT_STRIPES * 2 * st.tc, bw.stat_ln)
                 ops.layernorm2d_bwd(sc.dtr, prev.F, ln.weight, st.tr_stat[0], st.tr_stat[1], Gp, s64, n, prev.h, prev.w, st.tc, code,
                                     x_coff=prev.coff, dx_coff=gpo, s2d=st.ds, c_pad=st.tcp, accumulate=prev.skip is not None)
-                self._ln_grads(bw, grads, ln, st.tc)
+                self._ln_grads(bw, grads, ln, st.tc, s64)
                 self._ready(grads, [ln.weight, ln.bias, conv.weight, conv.bias])
         # ---- stem
         st0 = p.stages[0]
         G0, g0o = bw.G[0]
         stem_conv, stem_ln = enc.stem.stem[0], enc.stem.stem[1]
         c0 = enc.n_init_features
-        s64 = bw.stat_ln[:ops.STAT_STRIPES * 2 * c0]
-        s64.zero_()
+        s64 = self._z64.take(ops.STAT_STRIPES * 2 * c0, bw.stat_ln)
         ops.layernorm2d_bwd(G0, p.stem_y, stem_ln.weight, p.stem_stat[0], p.stem_stat[1], bw.dstem, s64, n, st0.h, st0.w, c0, code,
                             g_coff=g0o, c_pad=c0)
-        self._ln_grads(bw, grads, stem_ln, c0)
+        self._ln_grads(bw, grads, stem_ln, c0, s64)
         self._bias_grad(bw, grads, stem_conv.bias, bw.dstem, st0.npix, c0, code)
         self._wgrad1x1(p, grads, stem_conv, bw.dstem, c0, 0, p.xpatch, self.pc, st0.h, st0.w, mode=2)
         ops.conv2d(bw.dstem, ops.pad_to(c0, 16), self._pw(stem_conv, "dgrad", code, mode=3), bw.dxpatch, self.pc, n=n, h=st0.h, w=st0.w)
