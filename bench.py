@@ -229,10 +229,23 @@ def main():
         pool = torch.cuda.graph_pool_handle()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
+        state = {"g": None}
+
+        def switch():
+            g1.capture_end(); state["g"] = None
+            g2.capture_begin(pool=pool); state["g"] = g2
         with torch.cuda.stream(cap):
-            g1.capture_begin(pool=pool)
-            body(lambda: (g1.capture_end(), g2.capture_begin(pool=pool)))
-            g2.capture_end()
+            try:
+                g1.capture_begin(pool=pool); state["g"] = g1
+                body(switch)
+                g2.capture_end(); state["g"] = None
+            except Exception:
+                if state["g"] is not None:          # leave no stream in capture mode behind: the caller falls back to one graph
+                    try:
+                        state["g"].capture_end()
+                    except Exception:
+                        pass
+                raise
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         return g1, g2, eng.grad_split_offset()
