@@ -423,6 +423,15 @@ int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image);
 int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat, uint8_t* hr_norm, uint8_t* hr_hat_norm, int n_images,
                             int64_t pixels_per_image, float pmin, float pmax, void* workspace, pssr_stream_t stream);
 
+/* Per-image restoration metrics of uint8 image pairs [n_images][h][w] resident in HBM, as pssr/predict.py:193-203 computes them
+ * through skimage.metrics (peak_signal_noise_ratio, structural_similarity with data_range 255: uniform 7x7 window, K1 .01,
+ * K2 .03, sample covariance, mean over the interior).  out[i] = { sum of squared differences (exact integer in a double),
+ * mean SSIM }: mse = out[0] / (h w 255^2), psnr = 10 log10(255^2 h w / out[0]).  h, w >= 7 (skimage raises below that too).
+ * workspace: pssr_image_metrics_workspace_bytes(n_images, h, w) bytes.  Reproducible bit for bit (fixed summation order). */
+int64_t pssr_image_metrics_workspace_bytes(int n_images, int h, int w);
+int pssr_image_metrics_u8(const uint8_t* hr, const uint8_t* hr_hat, double* out, int n_images, int h, int w, void* workspace,
+                          pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,86 @@ __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __re
     for (int i = tid; i < n; i += NT) { out_hr[i] = out_a[hr[i]]; out_hat[i] = out_b[hat[i]]; }
 }
 
+
+// ---- PSNR / SSIM of uint8 image pairs (pssr/predict.py:199-203 -> skimage.metrics.peak_signal_noise_ratio /
+// structural_similarity with data_range 255: uniform 7x7 window, K1 = .01, K2 = .03, sample covariance, mean over the interior
+// that a full window covers).  Window sums of a, b, a^2, b^2, ab over bytes are exact in 32-bit integers, so the local
+// statistics are computed from exact sums (the reference's float64 running sums round in the 16th digit) and only the SSIM
+// expression itself is float64; the squared-difference sum is an exact 64-bit integer.  Per-tile float64 partials are written
+// to the workspace and summed in a fixed order, so the result is reproducible bit for bit.
+constexpr int MT = 32, MW = 7, MH = MT + MW - 1;      // 32x32 output pixels per workgroup, 38x38 input halo
+
+__global__ void __launch_bounds__(NT) ssim_tiles_kernel(const uint8_t* __restrict__ hr_all, const uint8_t* __restrict__ hat_all,
+                                                        double* __restrict__ partial, int h, int w, int tiles_x, int tiles) {
+    __shared__ uint8_t A[MH][MH + 2], B[MH][MH + 2];
+    __shared__ unsigned HS[5][MH][MT];
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x, tile = blockIdx.x, img = blockIdx.y;
+    const int ty0 = tile / tiles_x * MT, tx0 = tile % tiles_x * MT;      // top-left of the tile in interior (output) coordinates
+    const uint8_t* hr = hr_all + (long)img * h * w;
+    const uint8_t* hat = hat_all + (long)img * h * w;
+    for (int i = tid; i < MH * MH; i += NT) {
+        const int r = i / MH, c = i % MH, y = ty0 + r, x = tx0 + c;
+        const bool in = y < h && x < w;
+        A[r][c] = in ? hr[(long)y * w + x] : 0;
+        B[r][c] = in ? hat[(long)y * w + x] : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < MH * MT; i += NT) {
+        const int r = i / MT, c = i % MT;
+        unsigned sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+#pragma unroll
+        for (int k = 0; k < MW; ++k) {
+            const unsigned a = A[r][c + k], b = B[r][c + k];
+            sa += a; sb += b; saa += a * a; sbb += b * b; sab += a * b;
+        }
+        HS[0][r][c] = sa; HS[1][r][c] = sb; HS[2][r][c] = saa; HS[3][r][c] = sbb; HS[4][r][c] = sab;
+    }
+    __syncthreads();
+    const double inv = 1.0 / (MW * MW), cov_norm = (double)(MW * MW) / (MW * MW - 1);
+    const double c1 = (0.01 * 255) * (0.01 * 255), c2 = (0.03 * 255) * (0.03 * 255);
+    double acc = 0.0;
+    for (int i = tid; i < MT * MT; i += NT) {
+        const int r = i / MT, c = i % MT;
+        if (ty0 + r >= h - (MW - 1) || tx0 + c >= w - (MW - 1)) continue;
+        unsigned s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < MW; ++k)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s[q] += HS[q][r + k][c];
+        const double ux = s[0] * inv, uy = s[1] * inv, uxx = s[2] * inv, uyy = s[3] * inv, uxy = s[4] * inv;
+        const double vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+        const double a1 = 2 * ux * uy + c1, a2 = 2 * vxy + c2, b1 = ux * ux + uy * uy + c1, b2 = vx + vy + c2;
+        acc += (a1 * a2) / (b1 * b2);
+    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[(long)img * tiles + tile] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[img] = {sum of squared differences (exact), mean SSIM}; one workgroup per image, fixed summation order
+__global__ void __launch_bounds__(NT) image_metrics_finish_kernel(const uint8_t* __restrict__ hr_all, const uint8_t* __restrict__ hat_all,
+                                                                  const double* __restrict__ partial, double* __restrict__ out, long px,
+                                                                  int tiles, long interior) {
+    __shared__ unsigned long long sred[NT];
+    __shared__ double dred[NT];
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const uint8_t* hr = hr_all + img * px;
+    const uint8_t* hat = hat_all + img * px;
+    unsigned long long ssd = 0;
+    for (long i = tid; i < px; i += NT) { const int d = (int)hr[i] - (int)hat[i]; ssd += (unsigned)(d * d); }
+    double s = 0.0;
+    for (int i = tid; i < tiles; i += NT) s += partial[(long)img * tiles + i];
+    sred[tid] = ssd; dred[tid] = s;
+    __syncthreads();
+    for (int o = NT / 2; o; o >>= 1) {
+        if (tid < o) { sred[tid] += sred[tid + o]; dred[tid] += dred[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[2 * img] = (double)sred[0]; out[2 * img + 1] = dred[0] / (double)interior; }
+}
+
 }  // namespace
 
 extern "C" int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image) {
@@ -196,6 +276,32 @@ extern "C" int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat,
     PSSR_CHECK(pmin >= 0.f && pmax <= 100.f && pmin <= pmax, PSSR_ERR_ARG, "normalize_preds: percentiles");
     hipLaunchKernelGGL(normalize_preds_kernel, dim3(n_images), dim3(NT), 0, (hipStream_t)s, hr, hr_hat, hr_norm, hr_hat_norm, (int)pixels_per_image,
                        pmin, pmax, (char*)workspace, (long)pssr_normalize_preds_workspace_bytes(pixels_per_image));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+static inline int metric_tiles(int h, int w, int* tiles_x) {
+    const int tx = (w - (MW - 1) + MT - 1) / MT, ty = (h - (MW - 1) + MT - 1) / MT;
+    if (tiles_x) *tiles_x = tx;
+    return tx * ty;
+}
+
+extern "C" int64_t pssr_image_metrics_workspace_bytes(int n_images, int h, int w) {
+    if (n_images <= 0 || h < MW || w < MW) return 0;
+    return (int64_t)n_images * metric_tiles(h, w, nullptr) * (int64_t)sizeof(double);
+}
+
+extern "C" int pssr_image_metrics_u8(const uint8_t* hr, const uint8_t* hr_hat, double* out, int n_images, int h, int w, void* workspace,
+                                     pssr_stream_t s) {
+    PSSR_CHECK(hr && hr_hat && out && workspace && n_images > 0 && n_images <= 65535, PSSR_ERR_ARG, "image_metrics: null pointer / image count");
+    PSSR_CHECK(h >= MW && w >= MW && h <= 32768 && w <= 32768, PSSR_ERR_ARG,
+               "image_metrics: %dx%d image (the 7x7 SSIM window must fit, as in skimage; at most 32768 a side)", h, w);
+    int tiles_x;
+    const int tiles = metric_tiles(h, w, &tiles_x);
+    hipLaunchKernelGGL(ssim_tiles_kernel, dim3(tiles, n_images), dim3(NT), 0, (hipStream_t)s, hr, hr_hat, (double*)workspace, h, w, tiles_x, tiles);
+    PSSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(image_metrics_finish_kernel, dim3(n_images), dim3(NT), 0, (hipStream_t)s, hr, hr_hat, (const double*)workspace, out,
+                       (long)h * w, tiles, (long)(h - (MW - 1)) * (w - (MW - 1)));
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

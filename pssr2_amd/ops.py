@@ -485,3 +485,21 @@ def normalize_preds_u8(hr, hr_hat, pmin=0.1, pmax=99.9):
     L.check(lib.pssr_normalize_preds_u8(L.ptr(hr), L.ptr(hr_hat), L.ptr(a), L.ptr(b), n, C.c_int64(px), C.c_float(pmin), C.c_float(pmax), L.ptr(ws),
                                         L.stream_ptr()), "pssr_normalize_preds_u8")
     return a, b
+
+
+def image_metrics_u8(hr, hr_hat):
+    """uint8 device tensors [..., H, W] of equal shape -> float64 device tensor [n, 2]: per image the exact sum of squared differences
+    and the mean SSIM as skimage.metrics.structural_similarity(data_range=255) defines it (pssr/predict.py:199-203)."""
+    if hr.dtype != torch.uint8 or hr_hat.dtype != torch.uint8 or hr.shape != hr_hat.shape or not hr.is_cuda or hr.dim() < 2:
+        raise ValueError("image_metrics_u8 needs two uint8 device tensors of the same shape [..., H, W]")
+    hr, hr_hat = hr.contiguous(), hr_hat.contiguous()
+    h, w = hr.shape[-2:]
+    if min(h, w) < 7:
+        raise ValueError("win_size exceeds image extent: the 7x7 SSIM window needs images of at least 7x7 pixels")
+    n = hr.numel() // (h * w)
+    lib = L.lib()
+    lib.pssr_image_metrics_workspace_bytes.restype = C.c_int64
+    ws = torch.empty(lib.pssr_image_metrics_workspace_bytes(n, h, w), dtype=torch.uint8, device=hr.device)
+    out = torch.empty(n, 2, dtype=torch.float64, device=hr.device)
+    L.check(lib.pssr_image_metrics_u8(L.ptr(hr), L.ptr(hr_hat), L.ptr(out), n, h, w, L.ptr(ws), L.stream_ptr()), "pssr_image_metrics_u8")
+    return out

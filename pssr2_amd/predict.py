@@ -31,6 +31,16 @@ def _pred_array(data: torch.Tensor, n_frames: int = 1):
     return _slice_center(out.cpu().numpy(), n_frames)
 
 
+def _pred_tensor(data: torch.Tensor, n_frames: int = 1):
+    """``_pred_array`` that leaves the uint8 result in HBM (for the device-side normalisation and metrics)."""
+    if not data.is_cuda:
+        raise RuntimeError("pssr2_amd.predict runs on an MI355X (HIP) device only; there is no CPU fallback")
+    x = data.detach().contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    ops.clip_u8(x, out)
+    return _slice_center(out, n_frames)
+
+
 def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batch_size=None, out_dir: str = "preds", norm: bool = False,
                    prefix: str = None, dataloader_kwargs=None, callbacks=None):
     r"""Predicts high-resolution images for ``dataset.val_idx``; returns ``{name: uint8 [C,H,W]}`` when
@@ -122,12 +132,13 @@ def predict_sheet(model: nn.Module, sheet, tile_res: int = 128, overlap: int = 3
 def test_metrics(model: nn.Module, dataset: Dataset, device: str = "cpu", metrics=("mse", "pixel", "psnr", "ssim"), avg: bool = True,
                  norm: bool = True, callbacks=None):
     r"""Image restoration metrics of predicted vs ground truth images over ``dataset.val_idx`` (pssr/predict.py:144-211): same
-    arguments and return value.  Prediction, uint8 cast and (``norm``) intensity normalisation run on the MI355X; ``psnr`` and
-    ``ssim`` follow scikit-image's definitions (10 log10(255^2 / mse); uniform 7x7 windows, sample covariance) in float64.
-    Like the reference (pssr/predict.py:180) every iteration evaluates ``dataset[0]``."""
+    arguments and return value.  Prediction, uint8 cast, (``norm``) intensity normalisation and the per-image statistics all run on
+    the MI355X (csrc/metrics.hip): the squared-difference sum is an exact integer and ``ssim`` is scikit-image's
+    ``structural_similarity(data_range=255)`` (uniform 7x7 windows, sample covariance, interior mean) evaluated from exact integer
+    window sums; only two doubles per image come back to the host.  Like the reference (pssr/predict.py:180) every iteration
+    evaluates ``dataset[0]``."""
     import math
-    import numpy as np
-    from .util import normalize_preds, pixel_metric
+    from .util import pixel_metric
     callbacks, callback_locals = _get_callbacks(callbacks)
     image_range = 255
     metrics = [metrics] if type(metrics) is str else list(metrics)
@@ -135,39 +146,33 @@ def test_metrics(model: nn.Module, dataset: Dataset, device: str = "cpu", metric
     model.to(device)
     model.eval()
 
-    def _ssim(a, b):
-        from scipy.ndimage import uniform_filter
-        a, b = a.astype(np.float64), b.astype(np.float64)
-        n = 49
-        ux, uy = uniform_filter(a, 7), uniform_filter(b, 7)
-        vx = n / (n - 1) * (uniform_filter(a * a, 7) - ux * ux)
-        vy = n / (n - 1) * (uniform_filter(b * b, 7) - uy * uy)
-        vxy = n / (n - 1) * (uniform_filter(a * b, 7) - ux * uy)
-        c1, c2 = (0.01 * image_range) ** 2, (0.03 * image_range) ** 2
-        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
-        return float(s[3:-3, 3:-3].mean())
-
     with torch.no_grad():
         for _ in tqdm(dataset.val_idx):
             hr, lr = dataset[0]
             hr, lr = hr.to(device).unsqueeze(0), lr.to(device).unsqueeze(0)
             hr_hat = model(lr)
-            hr, hr_hat = _pred_array(hr), _pred_array(hr_hat)
+            hr_dev, hat_dev = _pred_tensor(hr), _pred_tensor(hr_hat)
             crop_res = dataset.crop_res if not dataset.is_lr else dataset.crop_res * (hr_hat.shape[-1] // lr.shape[-1])
-            hr, hr_hat = hr[:, :, :crop_res, :crop_res], hr_hat[:, :, :crop_res, :crop_res]
+            hr_dev, hat_dev = hr_dev[:, :, :crop_res, :crop_res].contiguous(), hat_dev[:, :, :crop_res, :crop_res].contiguous()
             if norm:
-                hr, hr_hat = normalize_preds(np.ascontiguousarray(hr), np.ascontiguousarray(hr_hat))
-            for i in range(len(hr)):
-                mse = float(np.mean((hr[i] / image_range - hr_hat[i] / image_range) ** 2))
+                hr_dev, hat_dev = ops.normalize_preds_u8(hr_dev, hat_dev)
+            n, c, h, w = hr_dev.shape
+            if "ssim" in out and c > 1:
+                raise ValueError("ssim: multi-channel images form a volume thinner than the 7x7x7 window (scikit-image raises here too)")
+            stats = ops.image_metrics_u8(hr_dev, hat_dev).reshape(n, c, 2).cpu()
+            for i in range(n):
+                err = float(stats[i, :, 0].sum()) / (c * h * w)           # mean squared error at uint8 scale (exact sum)
+                mse = err / image_range ** 2
                 if "mse" in out:
                     out["mse"].append(mse)
                 if "pixel" in out:
                     out["pixel"].append(pixel_metric(mse, image_range))
                 if "psnr" in out:
-                    err = float(np.mean((hr[i].astype(np.float64) - hr_hat[i].astype(np.float64)) ** 2))
                     out["psnr"].append(10 * math.log10(image_range ** 2 / err) if err > 0 else float("inf"))
                 if "ssim" in out:
-                    out["ssim"].append(_ssim(hr[i].squeeze(), hr_hat[i].squeeze()))
+                    out["ssim"].append(float(stats[i, 0, 1]))
+            if any(callback_locals):
+                hr, hr_hat = hr_dev.cpu().numpy(), hat_dev.cpu().numpy()       # the arrays the reference's callbacks see
             for i, callback in enumerate(callbacks):
                 callback(locals()) if callback_locals[i] else callback()
     return {m: (sum(v) / len(v) if avg else v) for m, v in out.items()}

@@ -76,3 +76,60 @@ def test_normalize_preds_api_and_drivers():
     assert set(res) == {"mse", "pixel", "psnr", "ssim"} and all(np.isfinite(v) for v in res.values())
     per = test_metrics(model, ds, device="cuda", metrics=["psnr", "ssim"], avg=False, norm=False)
     assert len(per["psnr"]) == len(ds.val_idx) and -1.0 <= per["ssim"][0] <= 1.0
+
+
+@pytest.mark.parametrize("shape", [(1, 7, 7), (3, 64, 64), (2, 100, 37), (1, 38, 39), (1, 512, 512)])
+def test_image_metrics_vs_oracle(shape):
+    """Sum of squared differences exact; SSIM vs the scipy restatement of skimage's structural_similarity (float64, 1e-10)."""
+    from oracle import metrics_ref as M
+    from pssr2_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    hr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    hat = np.clip(hr.astype(np.int32) + rng.integers(-40, 41, size=shape), 0, 255).astype(np.uint8)
+    hat[0, :3] = 255 - hat[0, :3]                                                  # some strongly anti-correlated windows
+    got = ops.image_metrics_u8(torch.tensor(hr).cuda(), torch.tensor(hat).cuda()).cpu().numpy()
+    again = ops.image_metrics_u8(torch.tensor(hr).cuda(), torch.tensor(hat).cuda()).cpu().numpy()
+    assert np.array_equal(got, again)                                              # fixed summation order
+    for i in range(shape[0]):
+        ssd = int(((hr[i].astype(np.int64) - hat[i].astype(np.int64)) ** 2).sum())
+        assert got[i, 0] == ssd
+        assert abs(10 * np.log10(255.0 ** 2 * hr[i].size / got[i, 0]) - M.psnr(hr[i], hat[i])) < 1e-9      # bar: 1e-3 dB
+        assert abs(got[i, 1] - M.ssim(hr[i], hat[i])) < 1e-10
+
+
+def test_image_metrics_identical_and_argument_checks():
+    from pssr2_amd import ops
+    x = torch.randint(0, 256, (2, 1, 48, 48), dtype=torch.uint8, device="cuda")
+    got = ops.image_metrics_u8(x, x).cpu().numpy()
+    assert np.array_equal(got[:, 0], [0.0, 0.0]) and np.allclose(got[:, 1], 1.0, atol=1e-15)
+    with pytest.raises(ValueError):
+        ops.image_metrics_u8(x[..., :6, :], x[..., :6, :])                          # the 7x7 window does not fit (skimage raises too)
+    with pytest.raises(ValueError):
+        ops.image_metrics_u8(x, x.float())
+    with pytest.raises(ValueError):
+        ops.image_metrics_u8(x, x[:1])
+
+
+def test_test_metrics_values_match_oracle_on_the_arrays_it_evaluated():
+    """test_metrics' numbers against the oracle evaluated on the very uint8 arrays a reference-style callback receives
+    (pssr/predict.py:193-203: mse of the /255 images, pixel_metric, skimage psnr / ssim)."""
+    from oracle import metrics_ref as M
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import ArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import test_metrics
+    from pssr2_amd.util import pixel_metric
+    rng = np.random.default_rng(5)
+    torch.manual_seed(1)
+    model = ResUNet(hidden=[16, 32])
+    images = rng.integers(0, 256, size=(4, 1, 64, 64), dtype=np.uint8)
+    ds = ArrayDataset(images, hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(5), val_split=0.5, rotation=False)
+    seen = []
+    per = test_metrics(model, ds, device="cuda", avg=False, callbacks=[lambda loc: seen.append((loc["hr"].copy(), loc["hr_hat"].copy()))])
+    assert len(seen) == len(ds.val_idx)
+    for k, (hr, hat) in enumerate(seen):
+        mse = np.mean((hr[0] / 255 - hat[0] / 255) ** 2)
+        assert abs(per["mse"][k] - mse) <= 1e-12 * mse
+        assert abs(per["pixel"][k] - pixel_metric(mse, 255)) <= 1e-9
+        assert abs(per["psnr"][k] - M.psnr(hr[0], hat[0])) < 1e-9
+        assert abs(per["ssim"][k] - M.ssim(hr[0].squeeze(), hat[0].squeeze())) < 1e-10
