@@ -336,12 +336,18 @@ int pssr_input_patchify(const float* x_nchw, void* xpatch, int n, int c, int h, 
 /* Depthwise 7x7 conv, stride 1, zero padding 3 (nn.Conv2d(C, C, groups=C, kernel_size=7, padding=3), _rdnet.py:182,197).
  * pssr_dwconv7_pack: torch weight [C,1,7,7] f32 -> [49][C] f32 (flip = 1: rotated by 180 degrees, for the input gradient).
  * pssr_dwconv7: out (+)= bias + conv(in, packed)  (accumulate = 1 adds into `out`: the gradient of a dense-stage input
- * that several blocks read).  pssr_dwconv7_wgrad: dw[C][49] += sum_pixels dy * shifted x (f32 atomics, caller zeroes). */
+ * that several blocks read).  pssr_dwconv7_wgrad: dw[C][49] += sum_pixels dy * shifted x (f32 atomics, caller zeroes).
+ * pssr_dwconv7_wgrad_ws (w % 8 == 0): the same sums without atomics -- one [C][49] slab per workgroup in `workspace`
+ * (pssr_dwconv7_wgrad_workspace_bytes), added to dw in a fixed order: reproducible bit for bit, and not bound by the
+ * L2 atomic rate (2.7 M atomics on 21 k addresses cost ~150 us whatever the map size). */
 int pssr_dwconv7_pack(const float* w, float* packed, int c, int flip, pssr_stream_t stream);
 int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, const float* bias, void* out, int out_cs,
                  int out_co, int n, int h, int w, int c, int accumulate, int dtype, pssr_stream_t stream);
 int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h,
                        int w, int c, int dtype, pssr_stream_t stream);
+int64_t pssr_dwconv7_wgrad_workspace_bytes(int n, int h, int w, int c);
+int pssr_dwconv7_wgrad_ws(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h,
+                          int w, int c, int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t stream);
 /* timm LayerNorm2d (_rdnet.py:60,112,183,198): layer norm over the C channels of every pixel, eps inside the sqrt, affine.
  * Channels [c, c_pad) of the output are written as zeros (K padding of the following 1x1 conv).  s2d = 1 writes the
  * 2x2 space-to-depth layout out[n, y/2, x/2, ((y&1)*2 + (x&1))*c_pad + ch], which makes the stride-2 transition conv

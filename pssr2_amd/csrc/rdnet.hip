@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_seg_kernel(Ref dy, Ref x, f
 // per workgroup (the 7 ky threads hit the same lines) and an input row serves the 7 kernel rows on consecutive iterations
 // from L1/L2 -- the blockIdx.y version above streams both tensors 7 times from HBM.
 template <typename T>
-__global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, float* __restrict__ dw, int n, int h, int w, int c, long per_block) {
+__global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, float* __restrict__ dw, int n, int h, int w, int c, long per_block,
+                                                                 float* __restrict__ part) {
     const int cgc = c / 4, ws = w / 8;
     const int ky = threadIdx.x / 32, cg = blockIdx.y * 32 + threadIdx.x % 32;
     if (cg >= cgc) return;
@@ -292,11 +293,11 @@ __global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, 
     for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
-    for (long sgi = s0; sgi < s1; ++sgi) {
-        const int y = (int)(sgi % h);
-        const long t = sgi / h;
-        const int xs = (int)(t % ws) * 8;
-        const long img_base = (t / ws) * h * w;
+    for (int sgi = (int)s0; sgi < (int)s1; ++sgi) {             // nseg < 2^31 (checked by the launcher): 32-bit divisions
+        const int y = sgi % h;
+        const int t = sgi / h;
+        const int xs = (t % ws) * 8;
+        const long img_base = (long)(t / ws) * h * w;
         const int sy = y + ky - 3;
         if (sy < 0 || sy >= h) continue;
         float g[8][4], v[14][4];
@@ -322,10 +323,43 @@ __global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, 
                 acc[kx][0] = a01[0]; acc[kx][1] = a01[1]; acc[kx][2] = a23[0]; acc[kx][3] = a23[1];
             }
     }
+    if (part) {      // one slab [gridDim.y * 128 channels][49] per workgroup, summed in a fixed order by dwconv7_wgrad_reduce_kernel
+        float* slab = part + (long)blockIdx.x * gridDim.y * 128 * 49;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[(long)(cg * 4 + e) * 49 + ky * 7 + k] = acc[k][e];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(dw + (long)(cg * 4 + e) * 49 + ky * 7 + k, acc[k][e]);
+}
+
+// dw[i] += sum over the workgroup slabs in a fixed order (the depthwise weight gradient is reproducible bit for bit):
+// a workgroup owns 64 consecutive elements; 16 slab lanes each sum every 16th slab, then lane 0 adds the 16 sums in order.
+__global__ __launch_bounds__(1024) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int elems, long slab, int slabs) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < elems) {
+        int b = lane;
+        for (; b + 48 < slabs; b += 64) {
+            s0 += part[(long)b * slab + i]; s1 += part[(long)(b + 16) * slab + i];
+            s2 += part[(long)(b + 32) * slab + i]; s3 += part[(long)(b + 48) * slab + i];
+        }
+        for (; b < slabs; b += 16) s0 += part[(long)b * slab + i];
+    }
+    red[lane][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (lane == 0 && i < elems) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += red[l][col];
+        dw[i] += s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,9 +664,45 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
     return PSSR_OK;
 }
 
+// Workgroups along the row segments for the slab version: >= 4 segments each, ~1024 workgroups in all (16 waves per CU)
+static inline long dw_slab_blocks(int n, int h, int w, int c, long* per_block_out) {
+    const int gy = (c / 4 + 31) / 32;
+    const long nseg = (long)n * h * (w / 8);
+    long gs = 1024 / gy;
+    if (gs > nseg / 4) gs = nseg / 4;
+    if (gs < 1) gs = 1;
+    const long per_block = (nseg + gs - 1) / gs;
+    if (per_block_out) *per_block_out = per_block;
+    return (nseg + per_block - 1) / per_block;
+}
+
+int64_t pssr_dwconv7_wgrad_workspace_bytes(int n, int h, int w, int c) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4 || w % 8) return 0;
+    return dw_slab_blocks(n, h, w, c, nullptr) * ((c / 4 + 31) / 32) * 128 * 49 * (int64_t)sizeof(float);
+}
+
+int pssr_dwconv7_wgrad_ws(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h, int w, int c,
+                          int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t s) {
+    PSSR_CHECK(dy && x && dw && workspace && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && w % 8 == 0 && (long)n * h * w < (1L << 31), PSSR_ERR_ARG,
+               "dwconv7_wgrad_ws: bad args (w must be a multiple of 8)");
+    CHECK_REF("dwconv7_wgrad dy", dy_cs, dy_co, c); CHECK_REF("dwconv7_wgrad x", x_cs, x_co, c);
+    PSSR_CHECK(workspace_bytes >= pssr_dwconv7_wgrad_workspace_bytes(n, h, w, c), PSSR_ERR_ARG, "dwconv7_wgrad_ws: workspace of %ld bytes, %ld needed",
+               (long)workspace_bytes, (long)pssr_dwconv7_wgrad_workspace_bytes(n, h, w, c));
+    long per_block;
+    const long blocks = dw_slab_blocks(n, h, w, c, &per_block);
+    const int gy = (c / 4 + 31) / 32;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel<T>, dim3((unsigned)blocks, gy), dim3(224), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
+                                         Ref{x, x_cs, x_co}, dw, n, h, w, c, per_block, (float*)workspace));
+    PSSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3((c * 49 + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const float*)workspace, dw, c * 49,
+                       (long)gy * 128 * 49, (int)blocks);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
 int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h, int w, int c,
                        int dtype, pssr_stream_t s) {
-    PSSR_CHECK(dy && x && dw && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7_wgrad: bad args");
+    PSSR_CHECK(dy && x && dw && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && (long)n * h * w < (1L << 31), PSSR_ERR_ARG, "dwconv7_wgrad: bad args");
     CHECK_REF("dwconv7_wgrad dy", dy_cs, dy_co, c); CHECK_REF("dwconv7_wgrad x", x_cs, x_co, c);
     const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
     long gx = ((long)n * h * w + ppb - 1) / ppb / 16;       // >= 16 pixels per thread before the atomics
@@ -647,7 +717,7 @@ int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int 
         if (gs > nseg) gs = nseg;
         const long per_block = (nseg + gs - 1) / gs;
         DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel<T>, dim3((unsigned)((nseg + per_block - 1) / per_block), gy), dim3(224), 0, (hipStream_t)s,
-                                             Ref{dy, dy_cs, dy_co}, Ref{x, x_cs, x_co}, dw, n, h, w, c, per_block));
+                                             Ref{dy, dy_cs, dy_co}, Ref{x, x_cs, x_co}, dw, n, h, w, c, per_block, (float*)nullptr));
     } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_wgrad_kernel<T>, dim3((unsigned)gx, 7), dim3(TPB), 0, (hipStream_t)s, Ref{dy, dy_cs, dy_co},
                                              Ref{x, x_cs, x_co}, dw, n, h, w, c));

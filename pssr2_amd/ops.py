@@ -347,6 +347,14 @@ def dwconv7(x, wp, bias, out, n, h, w, c, dtype, in_coff=0, out_coff=0, accumula
 
 
 def dwconv7_wgrad(dy, x, dw, n, h, w, c, dtype, dy_coff=0, x_coff=0):
+    if w % 8 == 0:      # per-workgroup slabs summed in a fixed order (no atomics)
+        lib = L.lib()
+        lib.pssr_dwconv7_wgrad_workspace_bytes.restype = C.c_int64
+        nbytes = lib.pssr_dwconv7_wgrad_workspace_bytes(n, h, w, c)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dw.device)
+        L.check(lib.pssr_dwconv7_wgrad_ws(*_ref(dy, dy_coff), *_ref(x, x_coff), L.ptr(dw), n, h, w, c, dtype, L.ptr(ws), C.c_int64(nbytes),
+                                          L.stream_ptr()), "pssr_dwconv7_wgrad_ws")
+        return
     L.check(L.lib().pssr_dwconv7_wgrad(*_ref(dy, dy_coff), *_ref(x, x_coff), L.ptr(dw), n, h, w, c, dtype, L.stream_ptr()), "pssr_dwconv7_wgrad")
 
 

@@ -42,7 +42,7 @@ def test_patchify():
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(2, 24, 9, 13), (1, 264, 16, 16), (3, 8, 4, 4), (2, 40, 6, 24), (1, 1040, 8, 8)])
+@pytest.mark.parametrize("shape", [(2, 24, 9, 13), (1, 264, 16, 16), (3, 8, 4, 4), (2, 40, 6, 24), (1, 1040, 8, 8), (4, 136, 32, 32)])
 def test_dwconv7(shape, dt):
     from pssr2_amd import ops
     n, c, h, w = shape
@@ -71,6 +71,35 @@ def test_dwconv7(shape, dt):
     dw = torch.zeros(c, 49, device="cuda")
     ops.dwconv7_wgrad(dyd, xd, dw, n, h, w, c, code, x_coff=8)
     _close(dw.cpu().view(c, 1, 7, 7), wt.grad, dt, n * h * w)
+
+
+def test_dwconv7_wgrad_slabs_accumulate_and_are_reproducible():
+    """w % 8 == 0: per-workgroup slabs + fixed-order sum (no atomics) -- dw += ..., identical bits on every run; the workspace size is checked."""
+    from pssr2_amd import ops, _lib as L
+    import ctypes as C
+    n, c, h, w = 8, 200, 16, 24
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g)
+    dy = torch.randn(n, c, h, w, generator=g)
+    xd, dyd = _nhwc(x, c + 8, torch.float32, coff=4), _nhwc(dy, c, torch.float32)
+    code = ops.dtype_code(torch.float32)
+    runs = []
+    for _ in range(2):
+        dw = torch.full((c, 49), 0.5, device="cuda")
+        ops.dwconv7_wgrad(dyd, xd, dw, n, h, w, c, code, x_coff=4)
+        runs.append(dw.cpu())
+    assert torch.equal(runs[0], runs[1])
+    wt = torch.zeros(c, 1, 7, 7, requires_grad=True)
+    F.conv2d(x, wt, padding=3, groups=c).backward(dy)
+    ref = wt.grad.view(c, 49)
+    torch.testing.assert_close(runs[0] - 0.5, ref, rtol=2e-4, atol=2e-3)
+    lib = L.lib()
+    lib.pssr_dwconv7_wgrad_workspace_bytes.restype = C.c_int64
+    need = lib.pssr_dwconv7_wgrad_workspace_bytes(n, h, w, c)
+    assert need > 0 and lib.pssr_dwconv7_wgrad_workspace_bytes(n, h, 9, c) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    rc = lib.pssr_dwconv7_wgrad_ws(L.ptr(dyd), c, 0, L.ptr(xd), c + 8, 4, L.ptr(dw), n, h, w, c, code, L.ptr(ws), C.c_int64(need - 1), L.stream_ptr())
+    assert rc != 0                                           # too small a workspace is refused, not overrun
 
 
 @pytest.mark.parametrize("dt", DTS)
