@@ -6,6 +6,8 @@
 // RDNet (torch.cat of all previous features, _rdnet.py:132-138) is elided by writing every new
 // feature at its channel offset of one buffer per stage.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -210,6 +212,119 @@ __global__ __launch_bounds__(256) void dwconv7_seg_kernel(Ref in, const float* _
             store4(at<T>(out, prow + o, c0), acc[o]);
         }
     }
+}
+
+// LDS-tiled version of the row-segment kernel: a workgroup owns TY rows x 16 columns x 64 channels and stages their
+// (TY+6) x 22 input halo once (1.9x / 2.4x the tile instead of the 12x each thread of dwconv7_seg_kernel asks of L1 / L2:
+// consecutive workgroups of that kernel land on different XCDs, so most of those re-reads cross the fabric -- it ran at the
+// fabric's ~6 TB/s, not at the vector ALU's rate).  A thread is (channel group of 4, 8-pixel column segment, row).
+template <typename T> struct DwTile {
+    static constexpr int TX = 16, CT = 64, HX = TX + 6;
+    // LDS pixel stride = the 64 channels, row pitch 23 pixels (odd): the two rows that share a 32-lane LDS pass sit 128 B apart
+    // modulo the 256 B bank width, so the 8-byte reads of 16 channel groups x 2 rows are conflict-free without padding bytes
+    static constexpr int PS = CT * (int)sizeof(T), HXP = HX + 1;
+    static constexpr int W_BYTES = 49 * CT * 4;
+    static constexpr int lds_bytes(int ty) { return (ty + 6) * HXP * PS + W_BYTES; }
+};
+
+template <typename T, int TY>
+__global__ __launch_bounds__(32 * TY) void dwconv7_tile_kernel(Ref in, const float* __restrict__ wp, const float* __restrict__ bias, MRef out,
+                                                               int n, int h, int w, int c, int accumulate, int tiles_x, int tiles_y, int ctiles) {
+    using D = DwTile<T>;
+    using V = typename std::conditional<sizeof(T) == 2, uint2, uint4>::type;       // 4 channels of T
+    constexpr int NT = 32 * TY, HY = TY + 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;                                                   // [HY][23] pixels of PS bytes (22 used)
+    float* wl = (float*)(smem + HY * D::HXP * D::PS);                    // [49][64]
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int ct = b % ctiles; b /= ctiles;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int img = b / tiles_y;
+    const int x0 = tx * D::TX, y0 = ty * TY, cb = ct * D::CT;
+    const long img_base = (long)img * h * w;
+
+    // all of a thread's halo loads are issued before the first LDS write (a rolled loop waits for each load in turn)
+    constexpr int ITEMS = (HY * D::HX * 16 + NT - 1) / NT;
+    V stage[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int it = tid + k * NT;
+        const int cgi = it & 15, px = it >> 4;
+        const int col = px % D::HX, row = px / D::HX;
+        const int gy = y0 + row - 3, gx = x0 + col - 3;
+        V v = {};
+        if (it < HY * D::HX * 16 && gy >= 0 && gy < h && gx >= 0 && gx < w && cb + cgi * 4 < c)
+            v = *(const V*)at<T>(in, img_base + (long)gy * w + gx, cb + cgi * 4);
+        stage[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int it = tid + k * NT;
+        const int cgi = it & 15, px = it >> 4;
+        const int col = px % D::HX, row = px / D::HX;
+        if (it < HY * D::HX * 16) *(V*)(halo + (row * D::HXP + col) * D::PS + cgi * 4 * (int)sizeof(T)) = stage[k];
+    }
+    for (int it = tid; it < 49 * 16; it += NT) {
+        const int cgi = it & 15, tap = it >> 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cb + cgi * 4 < c) v = *(const float4*)(wp + (long)tap * c + cb + cgi * 4);
+        *(float4*)(wl + tap * D::CT + cgi * 4) = v;
+    }
+    __syncthreads();
+
+    const int cgi = tid & 15, xseg = (tid >> 5) & 1, row = (tid >> 6) * 2 + ((tid >> 4) & 1);
+    const int c0 = cb + cgi * 4, y = y0 + row, xs = x0 + xseg * 8;
+    if (c0 >= c || y >= h || xs >= w) return;
+    float acc[8][4];
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) load4(bias + c0, b4);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[o][e] = b4[e];
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        float v[14][4];
+        const char* hrow = halo + ((row + ky) * D::HXP + xseg * 8) * D::PS + cgi * 4 * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < 14; ++j) load4((const T*)(hrow + j * D::PS), v[j]);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float4 wv = *(const float4*)(wl + (ky * 7 + kx) * D::CT + cgi * 4);
+            const f32x2 w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const f32x2 a01 = __builtin_elementwise_fma(f32x2{v[o + kx][0], v[o + kx][1]}, w01, f32x2{acc[o][0], acc[o][1]});
+                const f32x2 a23 = __builtin_elementwise_fma(f32x2{v[o + kx][2], v[o + kx][3]}, w23, f32x2{acc[o][2], acc[o][3]});
+                acc[o][0] = a01[0]; acc[o][1] = a01[1]; acc[o][2] = a23[0]; acc[o][3] = a23[1];
+            }
+        }
+    }
+    const long prow = img_base + (long)y * w + xs;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (accumulate) {
+            float prev[4];
+            load4(at<T>(out, prow + o, c0), prev);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] += prev[e];
+        }
+        store4(at<T>(out, prow + o, c0), acc[o]);
+    }
+}
+
+template <typename T, int TY>
+static void launch_dw_tile(const void* in, int in_cs, int in_co, const float* wp, const float* bias, void* out, int out_cs, int out_co, int n, int h,
+                           int w, int c, int accumulate, hipStream_t s) {
+    using D = DwTile<T>;
+    static bool attr_set = false;
+    constexpr int LDS = D::lds_bytes(TY);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dwconv7_tile_kernel<T, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    const int tiles_x = (w + D::TX - 1) / D::TX, tiles_y = (h + TY - 1) / TY, ctiles = (c + D::CT - 1) / D::CT;
+    hipLaunchKernelGGL((dwconv7_tile_kernel<T, TY>), dim3((unsigned)((long)n * tiles_y * tiles_x * ctiles)), dim3(32 * TY), LDS, s, Ref{in, in_cs, in_co}, wp, bias,
+                       MRef{out, out_cs, out_co}, n, h, w, c, accumulate, tiles_x, tiles_y, ctiles);
 }
 
 // blockIdx.y = ky; a thread keeps one channel group and walks row segments of 8 pixels
@@ -653,7 +768,11 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
     PSSR_CHECK(in && w_packed && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7: bad args");
     CHECK_REF("dwconv7 in", in_cs, in_co, c); CHECK_REF("dwconv7 out", out_cs, out_co, c);
     const long total = (long)n * h * w * (c / 4);
-    if (w % 8 == 0) {
+    static const int tile_mode = [] { const char* e = getenv("PSSR_DWCONV_TILE"); return e ? atoi(e) : 1; }();
+    if (w % 8 == 0 && tile_mode && (long)n * ((h + 7) / 8) * ((w + 15) / 16) * ((c + 63) / 64) < (1L << 31)) {
+        if (h > 8) { DISPATCH_T(dtype, (launch_dw_tile<T, 16>(in, in_cs, in_co, w_packed, bias, out, out_cs, out_co, n, h, w, c, accumulate, (hipStream_t)s))); }
+        else { DISPATCH_T(dtype, (launch_dw_tile<T, 8>(in, in_cs, in_co, w_packed, bias, out, out_cs, out_co, n, h, w, c, accumulate, (hipStream_t)s))); }
+    } else if (w % 8 == 0) {
         DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv7_seg_kernel<T>, dim3(grid1d(total / 8, 1 << 20)), dim3(TPB), 0, (hipStream_t)s, Ref{in, in_cs, in_co},
                                              w_packed, bias, MRef{out, out_cs, out_co}, n, h, w, c, accumulate));
     } else {
