@@ -662,15 +662,21 @@ __global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scal
 }
 
 // Effective-SE gate: u[n][co] = b[co] + sum_ci W[co][ci] * s[n][ci];  gate = relu6(u + 3) / 6
-__global__ void ese_gate_kernel(const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ b, int n, int c,
-                                float* __restrict__ u, float* __restrict__ gate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ b, int n, int c,
+                                                       float* __restrict__ u, float* __restrict__ gate) {
+    // one wave per output: the lanes run along ci, so the row of W is read coalesced (a thread per output walks W with stride c)
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n * c) return;
     const int img = i / c, co = i % c;
-    float acc = b[co];
-    for (int ci = 0; ci < c; ++ci) acc = fmaf(w[(long)co * c + ci], s[(long)img * c + ci], acc);
-    u[i] = acc;
-    gate[i] = fminf(fmaxf(acc + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    float acc = 0.f;
+    for (int ci = lane; ci < c; ci += 64) acc = fmaf(w[(long)co * c + ci], s[(long)img * c + ci], acc);
+    for (int o = 32; o; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) {
+        acc += b[co];
+        u[i] = acc;
+        gate[i] = fminf(fmaxf(acc + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
 }
 
 // out[p, c] = t[p, c] * (gate ? gate[img][c] : 1) * gamma[c] + (add ? add[img][c] : 0)
@@ -728,6 +734,91 @@ __global__ void ese_bwd_kernel(int stage, const float* __restrict__ A, const flo
         float a = 0.f;
         for (int co = 0; co < c; ++co) a = fmaf(w[(long)co * c + ci], du[(long)img * c + co], a);
         add[i] = a * inv_hw;
+    }
+}
+
+// The gate path of ese_bwd in one launch (four dependent launches of a few workgroups each cost ~20 us apiece in a step):
+// du is cheap to recompute, so the three reductions do not have to wait for it.  Workgroup roles by blockIdx.x:
+//   [0, n*cdiv(c,64))       (image, 64 input channels): du row (to LDS and to `du`), then add[img][ci] = inv_hw * sum_co W[co][ci] * du[img][co]
+//   next cdiv(c*c,256)      dWfc[co][ci] = sum_k du[k][co] * s[k][ci]
+//   the rest                dgamma[c] = sum_k A*gate ; dbfc[c] = sum_k du
+constexpr int ESE_MAX_C = 2048;
+__global__ __launch_bounds__(256) void ese_bwd_fused_kernel(const float* __restrict__ A, const float* __restrict__ gate, const float* __restrict__ u,
+                                                            const float* __restrict__ gamma, const float* __restrict__ s, const float* __restrict__ w,
+                                                            int n, int c, float inv_hw, float* __restrict__ du, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbfc, float* __restrict__ dwfc, float* __restrict__ add) {
+    __shared__ float dul[ESE_MAX_C];
+    const int tid = threadIdx.x;
+    auto du_at = [&](int k, int co) {
+        const float uv = u[(long)k * c + co];
+        return (uv > -3.f && uv < 3.f) ? A[(long)k * c + co] * gamma[co] * (1.f / 6.f) : 0.f;
+    };
+    const int nw = (c * c + 255) / 256;
+    int b = blockIdx.x;
+    const int nchunk = (c + 63) / 64, nimg = n * nchunk;
+    if (b < nimg) {      // (image, chunk of 64 input channels): 4 thread groups share the sum over co
+        __shared__ float red[4][64];
+        const int img = b / nchunk, chunk = b % nchunk;
+        for (int co = tid; co < c; co += 256) {
+            const float d = du_at(img, co);
+            dul[co] = d;
+            if (chunk == 0) du[(long)img * c + co] = d;
+        }
+        __syncthreads();
+        const int ci = chunk * 64 + (tid & 63), g = tid >> 6;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (ci < c) {
+            int co = g;
+            for (; co + 12 < c; co += 16) {
+                a0 = fmaf(w[(long)co * c + ci], dul[co], a0); a1 = fmaf(w[(long)(co + 4) * c + ci], dul[co + 4], a1);
+                a2 = fmaf(w[(long)(co + 8) * c + ci], dul[co + 8], a2); a3 = fmaf(w[(long)(co + 12) * c + ci], dul[co + 12], a3);
+            }
+            for (; co < c; co += 4) a0 = fmaf(w[(long)co * c + ci], dul[co], a0);
+        }
+        red[g][tid & 63] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && ci < c) add[(long)img * c + ci] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * inv_hw;
+        return;
+    }
+    b -= nimg;
+    if (b < nw) {        // 256 consecutive (co, ci): the few co rows of du they need are recomputed once into LDS
+        const int i0 = b * 256, i = i0 + tid;
+        const int co0 = i0 / c, co1 = min((i0 + 255) / c, c - 1), nco = co1 - co0 + 1;
+        const bool cached = n * nco <= ESE_MAX_C;
+        if (cached) {
+            for (int q = tid; q < n * nco; q += 256) dul[q] = du_at(q / nco, co0 + q % nco);
+            __syncthreads();
+        }
+        if (i >= c * c) return;
+        const int co = i / c, ci = i % c;
+        float a0 = 0.f, a1 = 0.f;
+        if (cached) {
+            int k = 0;
+            for (; k + 2 <= n; k += 2) {
+                a0 = fmaf(dul[k * nco + co - co0], s[(long)k * c + ci], a0);
+                a1 = fmaf(dul[(k + 1) * nco + co - co0], s[(long)(k + 1) * c + ci], a1);
+            }
+            if (k < n) a0 = fmaf(dul[k * nco + co - co0], s[(long)k * c + ci], a0);
+        } else {
+            for (int k = 0; k < n; ++k) a0 = fmaf(du_at(k, co), s[(long)k * c + ci], a0);
+        }
+        dwfc[i] = a0 + a1;
+        return;
+    }
+    b -= nw;             // 64 channels x 4 groups of images
+    __shared__ float red2[2][4][64];
+    const int ch = b * 64 + (tid & 63), g = tid >> 6;
+    float a = 0.f, d = 0.f;
+    if (ch < c)
+        for (int k = g; k < n; k += 4) {
+            a = fmaf(A[(long)k * c + ch], gate[(long)k * c + ch], a);
+            d += du_at(k, ch);
+        }
+    red2[0][g][tid & 63] = a; red2[1][g][tid & 63] = d;
+    __syncthreads();
+    if (g == 0 && ch < c) {
+        dgamma[ch] = (red2[0][0][tid] + red2[0][1][tid]) + (red2[0][2][tid] + red2[0][3][tid]);
+        dbfc[ch] = (red2[1][0][tid] + red2[1][1][tid]) + (red2[1][2][tid] + red2[1][3][tid]);
     }
 }
 
@@ -895,7 +986,7 @@ int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int
 
 int pssr_ese_gate(const float* s_mean, const float* w_fc, const float* b_fc, int n, int c, float* u, float* gate, pssr_stream_t s) {
     PSSR_CHECK(s_mean && w_fc && b_fc && u && gate && n > 0 && c > 0, PSSR_ERR_ARG, "ese_gate: bad args");
-    hipLaunchKernelGGL(ese_gate_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, (hipStream_t)s, s_mean, w_fc, b_fc, n, c, u, gate);
+    hipLaunchKernelGGL(ese_gate_kernel, dim3(cdiv(n * c, 4)), dim3(256), 0, (hipStream_t)s, s_mean, w_fc, b_fc, n, c, u, gate);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -918,10 +1009,15 @@ int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float*
     const float inv_hw = 1.f / (float)hw;
     if (gate) {
         PSSR_CHECK(u && s_mean && w_fc && du && db_fc && dw_fc && add, PSSR_ERR_ARG, "ese_bwd: gate path needs u, s, W, du, db, dW, add");
-        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 0, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
-        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, st, 1, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
-        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c * c, TPB)), dim3(TPB), 0, st, 2, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
-        hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 3, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+        if (c <= ESE_MAX_C) {
+            hipLaunchKernelGGL(ese_bwd_fused_kernel, dim3(n * cdiv(c, 64) + cdiv(c * c, 256) + cdiv(c, 64)), dim3(256), 0, st, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw,
+                               du, dgamma, db_fc, dw_fc, add);
+        } else {
+            hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 0, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+            hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, st, 1, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+            hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c * c, TPB)), dim3(TPB), 0, st, 2, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+            hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(n * c, TPB)), dim3(TPB), 0, st, 3, A, gate, u, gamma, s_mean, w_fc, n, c, inv_hw, du, dgamma, db_fc, dw_fc, add);
+        }
     } else {
         hipLaunchKernelGGL(ese_bwd_kernel, dim3(cdiv(c, TPB)), dim3(TPB), 0, st, 1, A, (const float*)nullptr, u, gamma, s_mean, w_fc, n, c, inv_hw,
                            (float*)nullptr, dgamma, (float*)nullptr, dw_fc, add);

@@ -236,9 +236,10 @@ def test_gelu_fused_1x1(dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("ese", [True, False])
-def test_ese_layerscale(ese, dt):
+@pytest.mark.parametrize("c", [24, 328])
+def test_ese_layerscale(ese, dt, c):
     from pssr2_amd import ops
-    n, c, h, w = 3, 24, 5, 7
+    n, h, w = 3, 5, 7
     code = ops.dtype_code(dt)
     g = torch.Generator().manual_seed(2)
     t = torch.randn(n, c, h, w, generator=g).to(dt).float().requires_grad_(True)
