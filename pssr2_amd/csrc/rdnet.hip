@@ -539,26 +539,28 @@ __global__ void ln_fwd_kernel(Ref in, const float* __restrict__ gamma, const flo
 }
 
 // dx (+)= rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat));  stats += [sum_p g*xhat | sum_p g]
-template <typename T>
-__global__ void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __restrict__ gamma, const float* __restrict__ mean,
+// NIT = channel slices of 256 a lane walks (registers scale with it), NT = threads: few slices leave room for 16 waves per
+// workgroup, which share one flush of the statistics (the f64 atomics bound how many workgroups a launch can afford)
+template <typename T, int NIT, int NT>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __restrict__ gamma, const float* __restrict__ mean,
                               const float* __restrict__ rstd, MRef dx, int accumulate, long npix, int h, int w, int c, double* stats) {
-    __shared__ float lds[(TPB / 64) * 64 * 8];
+    __shared__ float lds[(NT / 64) * 64 * 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long wid = (long)blockIdx.x * (TPB / 64) + wv, nw = (long)gridDim.x * (TPB / 64);
+    const long wid = (long)blockIdx.x * (NT / 64) + wv, nw = (long)gridDim.x * (NT / 64);
     const float inv_c = 1.f / (float)c;
-    float dgam[LN_MAXIT][4], dbet[LN_MAXIT][4];
+    float dgam[NIT][4], dbet[NIT][4];
 #pragma unroll
-    for (int it = 0; it < LN_MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dgam[it][e] = dbet[it][e] = 0.f;
     for (long pix = wid; pix < npix; pix += nw) {
         const float mu = mean[pix], rs = rstd[pix];
         long opix; int cbase;
         ln_out_pos(pix, h, w, s2d, cpad, opix, cbase);
-        float xh[LN_MAXIT][4], gg[LN_MAXIT][4];
+        float xh[NIT][4], gg[NIT][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int it = 0; it < LN_MAXIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int c0 = (lane + 64 * it) * 4;
             if (c0 < c) {
                 float xv[4], gv[4], gm[4];
@@ -576,7 +578,7 @@ __global__ void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __re
         }
         const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
 #pragma unroll
-        for (int it = 0; it < LN_MAXIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int c0 = (lane + 64 * it) * 4;
             if (c0 < c) {
                 float o[4];
@@ -595,7 +597,7 @@ __global__ void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __re
     // block combine (4 waves) per iteration slice, then one f64 atomic per channel per block into a stripe
     double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
 #pragma unroll
-    for (int it = 0; it < LN_MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         if (64 * it * 4 >= c) break;
         __syncthreads();
 #pragma unroll
@@ -608,7 +610,7 @@ __global__ void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __re
                 for (int e = 0; e < 4; ++e) {
                     float a = 0.f, b = 0.f;
 #pragma unroll
-                    for (int q = 0; q < TPB / 64; ++q) { a += lds[(q * 64 + lane) * 8 + e]; b += lds[(q * 64 + lane) * 8 + 4 + e]; }
+                    for (int q = 0; q < NT / 64; ++q) { a += lds[(q * 64 + lane) * 8 + e]; b += lds[(q * 64 + lane) * 8 + 4 + e]; }
                     atomicAdd(st + c0 + e, (double)a);
                     atomicAdd(st + c + c0 + e, (double)b);
                 }
@@ -960,11 +962,20 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
     PSSR_CHECK(c_pad >= c && c_pad % 4 == 0 && (!s2d || (h % 2 == 0 && w % 2 == 0)), PSSR_ERR_ARG, "layernorm2d_bwd: c_pad / s2d");
     CHECK_REF("layernorm2d_bwd g", g_cs, g_co, (s2d ? 4 : 1) * c_pad); CHECK_REF("layernorm2d_bwd x", x_cs, x_co, c); CHECK_REF("layernorm2d_bwd dx", dx_cs, dx_co, c);
     const long npix = (long)n * h * w;
-    long blocks = (npix + TPB / 64 - 1) / (TPB / 64) / 8;    // >= 8 pixels per wave before the statistics are flushed
-    if (blocks < 1) blocks = 1;
-    if (blocks > 512) blocks = 512;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, c_pad,
-                                         Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats));
+    // >= 4 pixels per wave before the statistics are flushed, <= 512 workgroups (2c f64 atomics each)
+#define PSSR_LN_BWD(NIT_, NT_)                                                                                                              \
+    do {                                                                                                                                    \
+        long blocks = (npix + (NT_) / 64 - 1) / ((NT_) / 64) / 4;                                                                           \
+        if (blocks < 1) blocks = 1;                                                                                                         \
+        if (blocks > 512) blocks = 512;                                                                                                     \
+        DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NIT_, NT_>), dim3((unsigned)blocks), dim3(NT_), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, \
+                                             c_pad, Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats)); \
+    } while (0)
+    if (c <= 256) PSSR_LN_BWD(1, 1024);
+    else if (c <= 512) PSSR_LN_BWD(2, 1024);
+    else if (c <= 1024) PSSR_LN_BWD(4, 512);
+    else PSSR_LN_BWD(8, 256);
+#undef PSSR_LN_BWD
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
