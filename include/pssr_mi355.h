@@ -438,6 +438,17 @@ int64_t pssr_image_metrics_workspace_bytes(int n_images, int h, int w);
 int pssr_image_metrics_u8(const uint8_t* hr, const uint8_t* hr_hat, double* out, int n_images, int h, int w, void* workspace,
                           pssr_stream_t stream);
 
+/* Several small f32 device-to-device copies in one launch (host struct passed by value to the kernel): the hand-written
+ * backward pass moves side results (dbeta doubling as a bias gradient, centre taps, ...) into the flat gradient buffer the
+ * all-reduce and AdamW read (the reference leaves this to autograd's .grad accumulation). */
+#define PSSR_COPY_BATCH_MAX 16
+typedef struct pssr_copy_batch {
+    float* dst[PSSR_COPY_BATCH_MAX];
+    const float* src[PSSR_COPY_BATCH_MAX];
+    int64_t n[PSSR_COPY_BATCH_MAX];
+} pssr_copy_batch;
+int pssr_copy_f32_batch(const pssr_copy_batch* items, int n_items, pssr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

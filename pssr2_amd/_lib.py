@@ -58,6 +58,14 @@ class GatherItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("sh", C.c_int), ("sw", C.c_int), ("rot", C.c_int), ("flip_axis", C.c_int)]
 
 
+COPY_BATCH_MAX = 16
+
+
+class CopyBatch(C.Structure):
+    """struct pssr_copy_batch (include/pssr_mi355.h)."""
+    _fields_ = [("dst", C.c_void_p * COPY_BATCH_MAX), ("src", C.c_void_p * COPY_BATCH_MAX), ("n", C.c_int64 * COPY_BATCH_MAX)]
+
+
 class PackItem(C.Structure):
     """struct pssr_pack_item (include/pssr_mi355.h)."""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("n_perm", c_void_p),

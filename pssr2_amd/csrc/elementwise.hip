@@ -505,6 +505,16 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
     }
 }
 
+// Up to PSSR_COPY_BATCH_MAX small f32 copies in one launch (blockIdx.y = item): the engine moves ~10 tiny side results per
+// residual block into their gradient slots, and as memcpy nodes of the step graph each cost ~10 us
+__global__ __launch_bounds__(256) void copy_batch_kernel(pssr_copy_batch items) {
+    const int it = blockIdx.y;
+    float* __restrict__ dst = items.dst[it];
+    const float* __restrict__ src = items.src[it];
+    const long n = items.n[it];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) dst[i] = src[i];
+}
+
 __global__ void clip_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = fminf(fmaxf(in[i], 0.f), 255.f);
@@ -715,6 +725,20 @@ int pssr_nchw_to_nhwc(const float* in, void* out, int n, int c, int64_t hw, int 
     PSSR_CHECK(in && out && n > 0 && c > 0 && hw > 0 && out_cs >= c, PSSR_ERR_ARG, "nchw_to_nhwc: bad args");
     const long total = (long)n * hw * out_cs;
     DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, in, (T*)out, n, c, (long)hw, out_cs, scale));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_copy_f32_batch(const pssr_copy_batch* items, int n_items, pssr_stream_t s) {
+    PSSR_CHECK(items && n_items > 0 && n_items <= PSSR_COPY_BATCH_MAX, PSSR_ERR_ARG, "copy_f32_batch: 1..%d items", PSSR_COPY_BATCH_MAX);
+    int64_t longest = 0;
+    for (int i = 0; i < n_items; ++i) {
+        PSSR_CHECK(items->dst[i] && items->src[i] && items->n[i] > 0, PSSR_ERR_ARG, "copy_f32_batch: item %d is empty", i);
+        if (items->n[i] > longest) longest = items->n[i];
+    }
+    long gx = (longest + 255) / 256;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(copy_batch_kernel, dim3((unsigned)gx, n_items), dim3(256), 0, (hipStream_t)s, *items);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -27,6 +27,8 @@ def _log2(v: int) -> int:
     return l
 
 
+_COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
+
 class _Arena:
     """Bump allocator for the many small per-channel vectors (one memset zeroes all statistics)."""
 
@@ -222,14 +224,19 @@ class Engine:
 
     def _ready(self, grads, params):
         """Copy small side results into their slots and tell the reducer these parameters are final."""
-        idx = []
+        idx, moves = [], []
         for prm in params:
             i = self._gindex[id(prm)]
             g = grads.get(id(prm))
             if g is not None and g.data_ptr() != self._gviews[i].data_ptr():
-                self._gviews[i].copy_(g.view(prm.shape))
+                if _COPY_BATCH and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == self._gviews[i].numel():
+                    moves.append((self._gviews[i], g))                 # one launch for all of them (memcpy nodes cost ~10 us each)
+                else:
+                    self._gviews[i].copy_(g.view(prm.shape))
             grads[id(prm)] = self._gviews[i]
             idx.append(i)
+        if moves:
+            ops.copy_f32_batch(moves)
         if self.reducer is not None:
             self.reducer.mark_ready(idx)
 

@@ -511,3 +511,15 @@ def image_metrics_u8(hr, hr_hat):
     out = torch.empty(n, 2, dtype=torch.float64, device=hr.device)
     L.check(lib.pssr_image_metrics_u8(L.ptr(hr), L.ptr(hr_hat), L.ptr(out), n, h, w, L.ptr(ws), L.stream_ptr()), "pssr_image_metrics_u8")
     return out
+
+
+def copy_f32_batch(pairs):
+    """[(dst, src), ...] contiguous float32 device tensors of equal numel: all copied by one kernel launch per 16 pairs."""
+    for k in range(0, len(pairs), L.COPY_BATCH_MAX):
+        chunk = pairs[k:k + L.COPY_BATCH_MAX]
+        items = L.CopyBatch()
+        for i, (dst, src) in enumerate(chunk):
+            if dst.dtype != torch.float32 or src.dtype != torch.float32 or dst.numel() != src.numel() or not (dst.is_contiguous() and src.is_contiguous()):
+                raise ValueError("copy_f32_batch needs contiguous float32 tensors of equal size")
+            items.dst[i], items.src[i], items.n[i] = dst.data_ptr(), src.data_ptr(), dst.numel()
+        L.check(L.lib().pssr_copy_f32_batch(C.byref(items), len(chunk), L.stream_ptr()), "pssr_copy_f32_batch")

@@ -56,3 +56,22 @@ def test_bn_backward_elementwise_kernels(c):
     ops.bn_bwd_apply(dz, y.cuda(), a.cuda(), b.cuda(), cc.cuda(), dy, npix, c, code)
     want = torch.addcmul(torch.addcmul(cc, b, y.float()), a, want_dz.float())          # a*g + (b*y + c), as the kernel's fma order
     assert (dy.cpu().float() - want).abs().max() <= 2.0 ** -7 * want.abs().max()
+
+
+def test_copy_f32_batch():
+    """Many small device-to-device copies in one launch (16 per kernel): bit-exact, sizes from 1 to beyond one grid stride."""
+    from pssr2_amd import ops
+    g = torch.Generator().manual_seed(0)
+    sizes = [1, 3, 64, 257, 1024, 5000, 70000] * 3                               # 21 pairs -> two launches
+    srcs = [torch.randn(s, generator=g).cuda() for s in sizes]
+    flat = torch.zeros(sum(sizes) + 8, device="cuda")
+    dsts, o = [], 4
+    for s in sizes:
+        dsts.append(flat[o:o + s]); o += s
+    ops.copy_f32_batch(list(zip(dsts, srcs)))
+    assert all(torch.equal(d, s) for d, s in zip(dsts, srcs))
+    assert (flat[:4] == 0).all() and (flat[-4:] == 0).all()
+    with pytest.raises(ValueError):
+        ops.copy_f32_batch([(dsts[0], srcs[1])])
+    with pytest.raises(ValueError):
+        ops.copy_f32_batch([(dsts[0].double(), srcs[0].double())])
