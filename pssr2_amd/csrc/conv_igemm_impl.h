@@ -507,15 +507,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 
     // source 0 (TAPS0 taps) then the optional 1x1 source 1; the loads of the next chunk fly during the MFMAs
-    // split-K (p.ksplit > 1, single source): blockIdx.y multiplies chunks [cb, n0c) of its slice only
+    // split-K (p.ksplit > 1): blockIdx.y multiplies chunks [cb, n0c) of source 0 only
     int cb = 0, n0c = p.nchunks[0];
     if (p.ksplit > 1) {
         const int per = (n0c + p.ksplit - 1) / p.ksplit;
         cb = blockIdx.y * per;
         n0c = cb + per < n0c ? cb + per : n0c;
     }
-    const bool second = p.nchunks[1] > 0 && p.ksplit <= 1;
+    const bool second = p.nchunks[1] > 0 && (p.ksplit <= 1 || (int)blockIdx.y == p.ksplit - 1);   // the 1x1 source rides with the last (shortest) slice
     if (cb < n0c) PSSR_ISSUE(0, cb, TAPS0)
+    else if (second) PSSR_ISSUE(1, 0, 1)
     for (int i = cb; i < n0c; ++i) {
         PSSR_COMMIT(0, i, TAPS0)
         __syncthreads();
@@ -1046,7 +1047,7 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
     // split-K when the tiles do not fill the chip and K is long: ~384 workgroups, >= 4 chunks per slice, <= 8 slices
     int ksplit = 1;
-    if (BN >= 64 && a.nchunks[1] == 0 && a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
+    if (BN >= 64 && a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
         ksplit = (int)((384 + blocks - 1) / blocks);
         if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
         if (ksplit > 8) ksplit = 8;

@@ -229,3 +229,26 @@ def test_conv_wgrad(case, dt):
     dw2 = torch.full((cout, cin, ks, ks), 9.0, device="cuda")
     ops.unpack_conv_wgrad(parts, dw2, k_pad=cpad)
     np.testing.assert_allclose(dw2.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_conv2d_dual_source_split_k(dt):
+    """Few tiles, long K, two sources (the decoder's first conv + residual 1x1 on small maps): K is split over blockIdx.y and the
+    1x1 source rides with the last slice; odd chunk counts leave some slices short or empty."""
+    from pssr2_amd import ops, _lib as L
+    code = ops.dtype_code(dt)
+    for n, cin, cin1, cout, h, w in [(2, 416, 96, 128, 8, 8), (1, 1056, 64, 256, 8, 8), (2, 288, 160, 64, 16, 8)]:
+        g = torch.Generator().manual_seed(cin + cin1)
+        x = torch.randn(n, cin, h, w, generator=g).to(dt).float()
+        x1 = torch.randn(n, cin1, h, w, generator=g).to(dt).float()
+        w3 = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dt).float()
+        w1 = (torch.randn(cout, cin1, 1, 1, generator=g) / cin1 ** 0.5).to(dt).float()
+        b = torch.randn(cout, generator=g)
+        ref = F.relu(F.conv2d(x, w3, b, padding=1) + F.conv2d(x1, w1))
+        out = torch.empty(n, h, w, cout, dtype=dt, device="cuda")
+        pw3 = ops.pack_conv_weight(w3.cuda(), code)
+        pw1 = ops.pack_conv_weight(w1.cuda(), code)
+        ops.conv2d(_nhwc(x, cin, dt), cin, pw3, out, cout, n=n, h=h, w=w, bias=b.cuda(), x1=_nhwc(x1, cin1, dt), cin1=cin1, w1=pw1,
+                   flags=L.FLAG_RELU)
+        tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+        torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=tol, atol=tol * float(ref.abs().max()))
