@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
 // from one address), the weight slices of KC chunks are one contiguous run of the 1-tap packed layout, and a wave
 // multiplies 4 * KC MFMAs per stage -- the 9-tap loop's density without a halo.
 template <typename T, int BN, int GEO, int KC>
-__global__ __launch_bounds__(256) void conv_flat_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC <= 4 ? 3 : 2))) void conv_flat_kernel(const ConvArgs p) {
     using C = Cfg<BN, GEO>;
     using X = TT<T>;
     constexpr int EPS = X::EPS;
@@ -610,7 +610,14 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int h = lane >> 5, r = lane & 31;
-    const int bid = blockIdx.x;
+    // workgroups go round-robin to the 8 XCDs: renumber them so that consecutive tiles (the channel tiles of one pixel tile first)
+    // run back to back on ONE XCD -- its L2 then serves the shared input tile and merges the 256-byte output segments of a
+    // pixel row before they go to HBM (with bid % tiles_n on 8 different XCDs every L2 wrote its own fragment of each row)
+    int bid = blockIdx.x;
+    if (p.ksplit <= 1) {
+        const int per = gridDim.x >> 3;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+    }
     const int tn = bid % p.tiles_n;
     int tmi = bid / p.tiles_n;
     const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
