@@ -238,6 +238,10 @@ __global__ __launch_bounds__(32 * TY) void dwconv7_tile_kernel(Ref in, const flo
     float* wl = (float*)(smem + HY * D::HXP * D::PS);                    // [49][64]
     const int tid = threadIdx.x;
     int b = blockIdx.x;
+    {   // consecutive tiles on ONE XCD (workgroups go round-robin to the 8 XCDs): neighbouring tiles share their halo in its L2
+        const int per = gridDim.x >> 3;
+        if (b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
     const int ct = b % ctiles; b /= ctiles;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
@@ -402,7 +406,12 @@ __global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, 
     const int ky = threadIdx.x / 32, cg = blockIdx.y * 32 + threadIdx.x % 32;
     if (cg >= cgc) return;
     const long nseg = (long)n * ws * h;                        // segment index = (img * ws + xseg) * h + y: y fastest
-    const long s0 = (long)blockIdx.x * per_block, s1 = s0 + per_block < nseg ? s0 + per_block : nseg;
+    int bx = blockIdx.x;                                        // consecutive segment runs on ONE XCD: they share input rows in its L2
+    {
+        const int per = gridDim.x >> 3;
+        if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);
+    }
+    const long s0 = (long)bx * per_block, s1 = s0 + per_block < nseg ? s0 + per_block : nseg;
     float acc[7][4];
 #pragma unroll
     for (int k = 0; k < 7; ++k)
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(224) void dwconv7_wgrad_rows_kernel(Ref dy, Ref x, 
             }
     }
     if (part) {      // one slab [gridDim.y * 128 channels][49] per workgroup, summed in a fixed order by dwconv7_wgrad_reduce_kernel
-        float* slab = part + (long)blockIdx.x * gridDim.y * 128 * 49;
+        float* slab = part + (long)bx * gridDim.y * 128 * 49;
 #pragma unroll
         for (int k = 0; k < 7; ++k)
 #pragma unroll
