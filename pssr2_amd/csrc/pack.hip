@@ -76,8 +76,49 @@ __device__ __forceinline__ void pack_tiles33(const float* __restrict__ w, T* __r
     const int tid = threadIdx.x;
     const int n_tiles = n_pad / 128, tiles = (k_pad / KCH) * n_tiles;
     const int gk = m.mode == 0 ? m.ci_count : m.cout, gn = m.mode == 0 ? m.cout : m.ci_count;
+    // 16-byte source loads where four consecutive elements of a run are all inside the weight (runs start on 16-byte boundaries
+    // when cin and ci_begin are multiples of 4): the scalar walk below was ~1.3 TB/s, bound by its 72 dependent iterations per tile
+    const bool vec_ok = m.cin % 4 == 0 && m.ci_begin % 4 == 0 && ((size_t)w & 15) == 0;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int c = tile / n_tiles, n0 = (tile % n_tiles) * 128;
+        if (vec_ok) {
+            for (int l0 = tid * 4; l0 < 128 * KCH * 9; l0 += 1024) {
+                int nl[4], kl[4], ts[4];
+                bool ok[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int l = l0 + e;
+                    if (m.mode == 0) { nl[e] = l / (KCH * 9); const int r = l - nl[e] * (KCH * 9); kl[e] = r / 9; ts[e] = r - kl[e] * 9; }
+                    else { kl[e] = l / (128 * 9); const int r = l - kl[e] * (128 * 9); nl[e] = r / 9; ts[e] = r - nl[e] * 9; }
+                    ok[e] = c * KCH + kl[e] < gk && n0 + nl[e] < gn;
+                }
+                // the four elements are consecutive in memory iff they share the run (mode 0: same n; mode 1: same k)
+                const bool same_run = m.mode == 0 ? nl[0] == nl[3] : kl[0] == kl[3];
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (same_run && ok[0] && ok[3]) {
+                    const int k = c * KCH + kl[0], n = n0 + nl[0];
+                    const int o = m.mode == 0 ? n : k, ci = m.mode == 0 ? k : n;
+                    const int co = m.n_perm ? m.n_perm[o] : o;
+                    const float4 q = *(const float4*)(w + ((long)co * m.cin + m.ci_begin + ci) * 9 + ts[0]);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ok[e]) {
+                            const int k = c * KCH + kl[e], n = n0 + nl[e];
+                            const int o = m.mode == 0 ? n : k, ci = m.mode == 0 ? k : n;
+                            const int co = m.n_perm ? m.n_perm[o] : o;
+                            v[e] = w[((long)co * m.cin + m.ci_begin + ci) * 9 + ts[e]];
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + nl[e];
+                    const int tap = m.mode == 0 ? ts[e] : 8 - ts[e];
+                    *(T*)(lds + (tap * 128 + nl[e]) * 32 + (((kl[e] / EPS) ^ ((n >> 3) & 1)) << 4) + (kl[e] % EPS) * (int)sizeof(T)) = (T)v[e];
+                }
+            }
+        } else
         for (int l = tid; l < 128 * KCH * 9; l += 256) {
             int nl, kl, ts;
             if (m.mode == 0) { nl = l / (KCH * 9); const int r = l - nl * (KCH * 9); kl = r / 9; ts = r - kl * 9; }
