@@ -313,23 +313,33 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
         if (gy < H && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
         xs[i] = xv; ys[i] = yv;
     }
+    __syncthreads();
     if (l1_sum) {
+        // L1 term from the staged tile (its origin is the tile origin); the border weight of an interior pixel is the whole
+        // window sum, added in the same order as the clipped sums so the value is the same float
         constexpr int r5 = K / 2;
-        for (int i = tid; i < TS * TS; i += 256) {
-            const int gy = oy0 + i / TS, gx = ox0 + i % TS;
-            if (gy < H && gx < W) {
-                float sy = 0.f, sx = 0.f;
+        float wsum = 0.f;
 #pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const int yy = gy + t - r5, xx = gx + t - r5;
-                    if (yy >= 0 && yy < H) sy += win.g[t];
-                    if (xx >= 0 && xx < W) sx += win.g[t];
+        for (int t = 0; t < K; ++t) wsum += win.g[t];
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int r = i / TS, c = i % TS;
+            const int gy = oy0 + r, gx = ox0 + c;
+            if (gy < H && gx < W) {
+                float sy = wsum, sx = wsum;
+                if (gy < r5 || gy >= H - r5) {
+                    sy = 0.f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { const int yy = gy + t - r5; if (yy >= 0 && yy < H) sy += win.g[t]; }
                 }
-                l1 += fabsf(xp[(long)gy * W + gx] - yp[(long)gy * W + gx]) * sy * sx;
+                if (gx < r5 || gx >= W - r5) {
+                    sx = 0.f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { const int xx = gx + t - r5; if (xx >= 0 && xx < W) sx += win.g[t]; }
+                }
+                l1 += fabsf(xs[r * IN + c] - ys[r * IN + c]) * sy * sx;
             }
         }
     }
-    __syncthreads();
     // horizontal pass: item = (row, segment of SEG output columns)
     for (int it = tid; it < IN * NS; it += 256) {
         const int r = it / NS, c0 = (it % NS) * SEG;
