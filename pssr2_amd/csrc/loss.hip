@@ -499,6 +499,9 @@ __global__ __launch_bounds__(256, 2) void ssim_bwd_k(const float* __restrict__ X
     __syncthreads();
     const float l1c = l1_coef_p ? l1_coef_p[0] : 0.f;
     constexpr int r5 = K / 2;
+    float wsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < K; ++t) wsum += win.g[t];
     float* dxp = dX + (long)plane * H * W;
     for (int it = tid; it < TS * NS; it += 256) {
         const int c = it % TS, r0 = (it / TS) * SEG;
@@ -528,12 +531,17 @@ __global__ __launch_bounds__(256, 2) void ssim_bwd_k(const float* __restrict__ X
                 g += 0.25f * dcoarse[((long)plane * HC + cy) * WC + cx];
             }
             if (l1c != 0.f) {
-                float sy = 0.f, sx = 0.f;
+                // border weights: the whole window sum (added in the same order) for interior pixels, clipped sums on the border
+                float sy = wsum, sx = wsum;
+                if (gy < r5 || gy >= H - r5) {
+                    sy = 0.f;
 #pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const int yy = gy + t - r5, xx = gx + t - r5;
-                    if (yy >= 0 && yy < H) sy += win.g[t];
-                    if (xx >= 0 && xx < W) sx += win.g[t];
+                    for (int t = 0; t < K; ++t) { const int yy = gy + t - r5; if (yy >= 0 && yy < H) sy += win.g[t]; }
+                }
+                if (gx < r5 || gx >= W - r5) {
+                    sx = 0.f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { const int xx = gx + t - r5; if (xx >= 0 && xx < W) sx += win.g[t]; }
                 }
                 const float d = xv - yv;
                 g += l1c * sy * sx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
