@@ -57,7 +57,7 @@ class ConvTimer:
 
         def timed(x, cin0, w0, out, cout, **kw):
             w = kw["w"]
-            dominant = cout > 64 and w > 8 and w0.dtype == 1 and w0.taps == 9
+            dominant = cout > 64 and w > 8 and w0.dtype in (1, 2) and w0.taps == 9       # 16-bit storage (bf16 = 1, f16 = 2)
             if not dominant:
                 return timer.orig(x, cin0, w0, out, cout, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -366,7 +366,7 @@ def main():
         elapsed = t.item()
 
     measured_in = "timed region"
-    if rank == 0 and use_graph and args.dtype == "bf16":
+    if rank == 0 and use_graph and args.dtype in ("bf16", "fp16"):      # both 16-bit MFMA paths have the same dense peak
         # the timed region replayed a hipGraph; time the same kernels once more in an instrumented eager pass
         timer.install()
         eager = (lambda: (fwd_bwd(), opt.zero_grad())) if args.mode == "train" else (infer_body if args.mode == "infer" else (lambda: fn(0)))
@@ -411,8 +411,10 @@ def main():
                              "frac_of_bf16_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / PEAK_BF16_TFLOPS, 4)},
         }
         traffic, traffic_src = pmc_traffic(args.mode if args.model == 'resunet' else f'{args.model}_{args.mode}')
+        if args.dtype != "bf16" or args.lr_res != 128 or args.channels != 1 or args.batch != 32:
+            traffic, traffic_src = None, None          # the committed counter passes were taken on the default workload only
         if conv:
-            res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,BN=128,8x16 tile,9 taps> (3x3 conv fwd+dgrad, Cout>64)",
+            res["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel<{'f16' if args.dtype == 'fp16' else 'bf16'},BN=128,8x16 tile,9 taps> (3x3 conv fwd+dgrad, Cout>64)",
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                                "traffic_source": traffic_src,
