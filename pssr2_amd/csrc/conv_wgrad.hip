@@ -596,7 +596,9 @@ int launch_1x1(WgradArgs p, hipStream_t stream, int* query) {
     const int slabs = p.co_tiles * p.ci_tiles;
     int split;
     if (query != nullptr || p.parts > 0) {
-        split = cdiv(512, slabs);
+        static int target = 0;
+        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS_1X1"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+        split = cdiv(target, slabs);
         if (split > p.n_tiles) split = p.n_tiles;
         if (split < 1) split = 1;
         if (query != nullptr) { *query = split; return PSSR_OK; }
@@ -634,10 +636,13 @@ int launch_t(WgradArgs p, hipStream_t stream, int* query) {
     const int slabs = p.co_tiles * p.ci_tiles;
     int split;
     if (query != nullptr || p.parts > 0) {
-        // partial-slab mode: ~2 workgroups per CU; every workgroup stores its slab once (plain stores), so the
-        // extra traffic is split * |dW| written + read back by the unpack/reduce pass
+        // partial-slab mode: ~1 workgroup per CU; every workgroup stores its slab once (plain stores), so the
+        // extra traffic is split * |dW| written + read back by the unpack/reduce pass.  The weight gradients run on a second
+        // stream under the backward chain: with 512 workgroups they finished sooner but took more of the chip and twice the
+        // slab traffic from the kernels on that chain (measured per step, c2: 768 -> 14.2 ms, 512 -> 13.6, 384 -> 13.5,
+        // 256 -> 13.1, 192 -> 13.5, 128 -> 14.0)
         static int target = 0;
-        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
         split = cdiv(target, slabs);
         if (split > p.n_tiles) split = p.n_tiles;
         if (split < 1) split = 1;
