@@ -906,7 +906,8 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
 static inline long dw_slab_blocks(int n, int h, int w, int c, long* per_block_out) {
     const int gy = (c / 4 + 31) / 32;
     const long nseg = (long)n * h * (w / 8);
-    long gs = 1024 / gy;
+    static const int target = [] { const char* e = getenv("PSSR_DWWG_BLOCKS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
+    long gs = target / gy;
     if (gs > nseg / 4) gs = nseg / 4;
     if (gs < 1) gs = 1;
     const long per_block = (nseg + gs - 1) / gs;
