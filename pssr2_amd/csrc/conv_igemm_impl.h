@@ -1043,6 +1043,12 @@ bool use_v2(const ConvArgs& a) {
     return a.taps[0] == 9 && blocks >= 512;
 }
 
+// workgroups a split-K launch aims for (PSSR_IGEMM_KSPLIT overrides)
+static inline int ksplit_target() {
+    static const int v = [] { const char* e = getenv("PSSR_IGEMM_KSPLIT"); const int x = e ? atoi(e) : 384; return x > 0 ? x : 384; }();
+    return v;
+}
+
 template <typename T, int BN, int GEO, int TAPS0>
 int launch_t(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<BN, GEO>;
@@ -1055,7 +1061,7 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     // split-K when the tiles do not fill the chip and K is long: ~384 workgroups, >= 4 chunks per slice, <= 8 slices
     int ksplit = 1;
     if (BN >= 64 && a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
-        ksplit = (int)((384 + blocks - 1) / blocks);
+        ksplit = (int)((ksplit_target() + blocks - 1) / blocks);
         if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
         if (ksplit > 8) ksplit = 8;
     }
@@ -1095,7 +1101,7 @@ int launch_flat(const ConvArgs& a, hipStream_t stream) {
     const int stages = cdiv(a.nchunks[0], KC);
     int ksplit = 1;      // same policy as the 9-tap loop, in stages (a stage ~ a 9-tap chunk)
     if (BN >= 64 && a.epi != PSSR_EPI_FINAL && blocks < 192 && stages >= 4) {
-        ksplit = (int)((384 + blocks - 1) / blocks);
+        ksplit = (int)((ksplit_target() + blocks - 1) / blocks);
         if (ksplit > stages / 2) ksplit = stages / 2;
         if (ksplit > 8) ksplit = 8;
     }
