@@ -1,18 +1,13 @@
 // C ABI of the implicit-GEMM convolution (forward and input-gradient): argument checks and dispatch on the storage type.
 // The kernels live in conv_igemm_impl.h, compiled once per type by conv_igemm_{bf16,f16,f32}.hip.
-#include <stdlib.h>
-
 #include "conv_igemm_args.h"
 
 using pssr_conv::ConvArgs;
-int pssr_conv::g_v2_mode = -1;
-int pssr_conv::g_flat_mode = 1;
-int pssr_conv::g_big_mode = 1;
-using pssr_conv::g_v2_mode;
 
+// kept for ABI version 1 callers: pssr_set_option("IGEMM_V2", mode)
 extern "C" int pssr_conv2d_pipeline_mode(int mode) {
-    const int old = g_v2_mode;
-    if (mode >= 0 && mode <= 2) g_v2_mode = mode;
+    const int old = pssr_tunables().igemm_v2;
+    if (mode >= 0 && mode <= 2) pssr_tunables().igemm_v2 = mode;
     return old;
 }
 
@@ -81,8 +76,7 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
     a.epi8 = esz == 2 && d->epilogue != PSSR_EPI_FINAL && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 &&
              (d->epilogue == PSSR_EPI_STORE || (d->aux_coff % 8 == 0 && d->aux_cstride % 8 == 0));
-    { const char* e_ = getenv("PSSR_CONV_EPI8"); if (e_ && atoi(e_) == 0) a.epi8 = 0; }
-    { static int flat_env = -1; if (flat_env < 0) { const char* e_ = getenv("PSSR_IGEMM_FLAT"); flat_env = e_ ? atoi(e_) : 1; pssr_conv::g_flat_mode = flat_env; const char* b_ = getenv("PSSR_IGEMM_BIG"); pssr_conv::g_big_mode = b_ ? atoi(b_) : 1; } }
+    if (!pssr_tunables().conv_epi8) a.epi8 = 0;
     long ws_query = 0;
     if (query_ws) { a.ksplit = -1; a.ws = (float*)&ws_query; }
     else { a.ws = (float*)d->workspace; a.ksplit = d->workspace ? (int)(d->workspace_bytes / 1024) : 0; }

@@ -1,6 +1,7 @@
 // Launch arguments of the implicit-GEMM convolution kernels, shared by the C ABI (conv_igemm.hip) and the per-type builds.
 #pragma once
 #include "common.h"
+#include "tunables.h"
 
 namespace pssr_conv {
 
@@ -21,9 +22,6 @@ struct ConvArgs {
     int ksplit; float* ws;      // split-K: blockIdx.y owns a chunk range, raw accumulators go to ws (single-source convs only)
 };
 
-extern int g_big_mode;      // 256-pixel x 64-channel tiles for 3x3 layers of at least 16x16 pixels (0 off, 1 Cout <= 64, 2 all)
-extern int g_flat_mode;     // 1x1 convolutions through the stage-of-chunks kernel, defined in conv_igemm.hip
-extern int g_v2_mode;       // pipelined-main-loop switch, defined in conv_igemm.hip
 int launch_bf16(const ConvArgs& a, hipStream_t s);
 int launch_f16(const ConvArgs& a, hipStream_t s);
 int launch_f32(const ConvArgs& a, hipStream_t s);

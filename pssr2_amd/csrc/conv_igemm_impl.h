@@ -18,12 +18,9 @@
 #pragma once
 #include <type_traits>
 
-#include <stdlib.h>
-
 #include "conv_igemm_args.h"
 
 using pssr_conv::ConvArgs;
-using pssr_conv::g_v2_mode;
 
 namespace {
 
@@ -59,7 +56,16 @@ template <int BN, int GEO> struct Cfg {
     static constexpr int RED_BYTES = 4 * BN * 2 * 4;
     static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
+    static constexpr bool PERM = false;     // MFMA row r of a 32-row tile is pixel r of the tile's pixel order
 };
+
+// output pixel (within the workgroup's tile) of accumulator row `row` (0 .. WM*32-1) of row tile mi.  C::PERM (conv_v3.h): the
+// two image rows of a 32-row tile are interleaved so that every ds_read_b128 lane group reads one image row
+template <class C> __device__ __forceinline__ int epi_pixel(int row, int mi) {
+    int r = row & 31;
+    if constexpr (C::PERM) r = (((r >> 4) ^ (((r & 15) >= 4 && (r & 15) < 12) ? 1 : 0)) << 4) | (r & 15);
+    return (row >> 5) * C::MI * 32 + mi * 32 + r;
+}
 
 // Epilogue shared by both main loops: the accumulators leave through LDS so that bias / ReLU / residual tail / ReLU mask /
 // GELU derivative / f64 BatchNorm statistics run on pixel-major rows and the stores are coalesced along channels.
@@ -74,6 +80,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
     float* Red = (float*)(smem + C::E_BYTES);       // [4 waves][BN][2]
     constexpr int CG = BN / 4;                      // 4-channel groups per row
     constexpr int PASSES = C::WM * 32 * CG / 256;
+    // row tile 0 leaves its registers before the per-channel constants are loaded (with 128 accumulators per lane the
+    // epilogue otherwise spills)
+#pragma unroll
+    for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int col = wn * C::NJ * 32 + nj * 32 + r;
+            Es[row * BN + col] = acc[0][nj][e];
+        }
+    asm volatile("" ::: "memory");
     const int c4 = tid % CG;
     const int n_base = n0 + c4 * 4;
     const bool n_ok = n_base < p.cout;
@@ -94,21 +111,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi) {
-        if (mi) __syncthreads();
+        if (mi) {
+            __syncthreads();
 #pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
+            for (int nj = 0; nj < C::NJ; ++nj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int col = wn * C::NJ * 32 + nj * 32 + r;
-                Es[row * BN + col] = acc[mi][nj][e];
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int col = wn * C::NJ * 32 + nj * 32 + r;
+                    Es[row * BN + col] = acc[mi][nj][e];
+                }
+        }
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int piece = tid + ps * 256;
             const int row = piece / CG;
-            const int m = (row >> 5) * C::MI * 32 + mi * 32 + (row & 31);
+            const int m = epi_pixel<C>(row, mi);
             const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
             const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
             if (!(n_ok && gi < p.N && gy < p.H && gx < p.W)) continue;
@@ -197,6 +216,22 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     constexpr int CG = BN / 8, RP = 256 / CG;       // pieces per row, rows per pass
     constexpr int ROWS = C::WM * 32, PASSES = ROWS / RP;
     static_assert(PASSES >= 1 && ROWS % RP == 0, "pass geometry");
+    int wcol[C::NJ];
+#pragma unroll
+    for (int nj = 0; nj < C::NJ; ++nj) {
+        const int col = wn * C::NJ * 32 + nj * 32 + r;
+        wcol[nj] = ((col >> 2) & 1) * (BN / 2) + ((col >> 3) << 2) + (col & 3);
+    }
+    // row tile 0 leaves its registers before the per-channel constants are loaded (with 128 accumulators per lane the
+    // epilogue otherwise spills)
+#pragma unroll
+    for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            Es[row * BN + wcol[nj]] = acc[0][nj][e];
+        }
+    asm volatile("" ::: "memory");
     const int c8 = tid % CG, row0 = tid / CG;
     const int n_base = n0 + c8 * 8;
     const bool n_ok = n_base < p.cout;
@@ -220,28 +255,24 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     T* outp = (T*)p.out + p.out_co + n_base;
     const T* auxp = (const T*)p.aux + p.aux_co + n_base;
-    int wcol[C::NJ];
-#pragma unroll
-    for (int nj = 0; nj < C::NJ; ++nj) {
-        const int col = wn * C::NJ * 32 + nj * 32 + r;
-        wcol[nj] = ((col >> 2) & 1) * (BN / 2) + ((col >> 3) << 2) + (col & 3);
-    }
 
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi) {
-        if (mi) __syncthreads();
+        if (mi) {
+            __syncthreads();
 #pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
+            for (int nj = 0; nj < C::NJ; ++nj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                Es[row * BN + wcol[nj]] = acc[mi][nj][e];
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    Es[row * BN + wcol[nj]] = acc[mi][nj][e];
+                }
+        }
         __syncthreads();
 #pragma unroll 1
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = row0 + ps * RP;
-            const int m = (row >> 5) * C::MI * 32 + mi * 32 + (row & 31);
+            const int m = epi_pixel<C>(row, mi);
             const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
             const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
             if (!(n_ok && gi < p.N && gy < p.H && gx < p.W)) continue;
@@ -298,27 +329,31 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
 }
 
 // picks the straight-line 8-channel epilogue when the layout allows (p.epi8, set by the host), else the generic one
+// the straight-line 8-channel epilogue of p.epi (16-bit storage, p.epi8 layouts only)
+template <typename T, int BN, class C>
+__device__ __forceinline__ void conv_epilogue8_any(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
+    const bool st = p.flags & PSSR_FLAG_STATS;
+    switch (p.epi) {
+    case PSSR_EPI_STORE:
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, true>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        return;
+    case PSSR_EPI_TAIL: conv_epilogue8<T, BN, C, PSSR_EPI_TAIL, false>(p, acc, smem, tid, x0, y0, img0, n0); return;
+    case PSSR_EPI_DGRAD_MASK:
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, true>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        return;
+    default:
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, true>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        return;
+    }
+}
+
 template <typename T, int BN, class C>
 __device__ __forceinline__ void conv_epilogue_any(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
     if constexpr (sizeof(T) == 2) {
-        if (p.epi8) {
-            const bool st = p.flags & PSSR_FLAG_STATS;
-            switch (p.epi) {
-            case PSSR_EPI_STORE:
-                if (st) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, true>(p, acc, smem, tid, x0, y0, img0, n0);
-                else conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false>(p, acc, smem, tid, x0, y0, img0, n0);
-                return;
-            case PSSR_EPI_TAIL: conv_epilogue8<T, BN, C, PSSR_EPI_TAIL, false>(p, acc, smem, tid, x0, y0, img0, n0); return;
-            case PSSR_EPI_DGRAD_MASK:
-                if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, true>(p, acc, smem, tid, x0, y0, img0, n0);
-                else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, false>(p, acc, smem, tid, x0, y0, img0, n0);
-                return;
-            default:
-                if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, true>(p, acc, smem, tid, x0, y0, img0, n0);
-                else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, false>(p, acc, smem, tid, x0, y0, img0, n0);
-                return;
-            }
-        }
+        if (p.epi8) { conv_epilogue8_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0); return; }
     }
     conv_epilogue<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
 }
@@ -766,6 +801,7 @@ template <int BN, int TAPS> struct Cfg2 {
     static constexpr int RING = 2;                                                  // weight stages resident in LDS
     static constexpr int MAIN_BYTES = 2 * A_BYTES + RING * B_BYTES;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
+    static constexpr bool PERM = false;
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -1027,6 +1063,87 @@ int launch2_t(const ConvArgs& a, hipStream_t stream) {
     return PSSR_OK;
 }
 
+}  // namespace
+#include "conv_v3.h"
+namespace {
+
+// second pass of a split-K v3 launch
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_splitk_finish3_kernel(const ConvArgs p) {
+    using C = Cfg3<BN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    const int tn = bid % p.tiles_n;
+    int tmi = bid / p.tiles_n;
+    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
+    const int tile_y = tmi % p.tiles_y;
+    const int img0 = tmi / p.tiles_y;
+    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, n0 = tn * BN;
+    f32x16 acc[C::MI][C::NJ];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+    for (int kz = 0; kz < p.ksplit; ++kz) {
+        const float4* src = (const float4*)p.ws + ((long)bid * p.ksplit + kz) * (4 * C::MI * C::NJ) * 256 + tid;
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = src[((mi * C::NJ + nj) * 4 + q) * 256];
+                    acc[mi][nj][4 * q] += v.x; acc[mi][nj][4 * q + 1] += v.y; acc[mi][nj][4 * q + 2] += v.z; acc[mi][nj][4 * q + 3] += v.w;
+                }
+    }
+    conv_epilogue8_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
+}
+
+// v3 launch: 16x16-pixel x 128-channel tiles; split-K when the tiles leave more than half of the 512 workgroup slots empty
+template <typename T, int BN>
+int launch3_t(const ConvArgs& a, hipStream_t stream) {
+    using C = Cfg3<BN>;
+    ConvArgs p = a;
+    p.tiles_x = cdiv(a.W, C::TW);
+    p.tiles_y = cdiv(a.H, C::TH);
+    p.tiles_n = cdiv(a.cout, BN);
+    const long blocks = (long)p.tiles_x * p.tiles_y * a.N * p.tiles_n;
+    PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
+    int ksplit = 1;
+    if (a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
+        ksplit = (int)((256 + blocks - 1) / blocks);
+        if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
+        if (ksplit > 8) ksplit = 8;
+    }
+    const int pro_lds = a.prologue == PSSR_PRO_BN_RELU ? a.nchunks[0] * TT<T>::KCH * 8 : 0;
+    PSSR_CHECK(pro_lds <= PRO_LDS_MAX, PSSR_ERR_UNSUPPORTED, "conv2d: BatchNorm prologue over %d input channels", a.nchunks[0] * TT<T>::KCH);
+    const long ws_bytes = ksplit > 1 ? blocks * ksplit * (long)(64 * C::MI * C::NJ) * 256 : 0;
+    if (a.ksplit < 0) { *(long*)a.ws = ws_bytes; return PSSR_OK; }
+    if (ksplit > 1 && (a.ws == nullptr || (long)a.ksplit * 1024 < ws_bytes)) ksplit = 1;
+    p.ksplit = ksplit;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + PRO_LDS_MAX);
+        (void)hipFuncSetAttribute((const void*)conv_splitk_finish3_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds, stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL((conv_splitk_finish3_kernel<T, BN>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+// v3 takes the 3x3 layers (16-bit storage) whose images hold a 16x16 tile; g_v3_mode 0 disables it (tests run both loops)
+template <typename T>
+bool use_v3(const ConvArgs& a) {
+    if constexpr (sizeof(T) != 2) return false;
+    return pssr_tunables().igemm_v3 != 0 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16 && a.prologue != PSSR_PRO_GELU && a.epi != PSSR_EPI_FINAL && a.epi8;
+}
+
 // the pipelined kernel needs >= 16x16 images and enough 256-pixel tiles to fill the chip (PSSR_IGEMM_V2=0 disables it)
 // 0 (default): off; 1: for 3x3 layers whose 256-pixel tiles fill the chip twice over; 2: whenever the shape allows (tests).
 // Round-1 measurement: correct (tests/test_gpu_conv.py runs every case with mode 2) but slower than the 128-pixel
@@ -1035,7 +1152,7 @@ int launch2_t(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int BN>
 bool use_v2(const ConvArgs& a) {
-    if (g_v2_mode < 0) { const char* e = getenv("PSSR_IGEMM_V2"); g_v2_mode = e ? atoi(e) : 0; }
+    const int g_v2_mode = pssr_tunables().igemm_v2;
     if (!g_v2_mode || a.W < 16 || a.H < 16 || a.ksplit < 0) return false;      // (ksplit < 0: workspace-size query)
     if (a.taps[0] == 1 && a.nchunks[1] != 0) return false;
     if (g_v2_mode == 2) return true;
@@ -1044,10 +1161,7 @@ bool use_v2(const ConvArgs& a) {
 }
 
 // workgroups a split-K launch aims for (PSSR_IGEMM_KSPLIT overrides)
-static inline int ksplit_target() {
-    static const int v = [] { const char* e = getenv("PSSR_IGEMM_KSPLIT"); const int x = e ? atoi(e) : 384; return x > 0 ? x : 384; }();
-    return v;
-}
+static inline int ksplit_target() { return pssr_tunables().igemm_ksplit; }
 
 template <typename T, int BN, int GEO, int TAPS0>
 int launch_t(const ConvArgs& a, hipStream_t stream) {
@@ -1084,8 +1198,6 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
     return PSSR_OK;
 }
 
-using pssr_conv::g_big_mode;
-using pssr_conv::g_flat_mode;     // 1 (default): 1x1 convolutions take conv_flat_kernel (PSSR_IGEMM_FLAT=0 disables)
 
 template <typename T, int BN, int GEO, int KC>
 int launch_flat(const ConvArgs& a, hipStream_t stream) {
@@ -1124,7 +1236,7 @@ int launch_flat(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int BN, int GEO>
 int launch(const ConvArgs& a, hipStream_t s) {
-    if (a.taps[0] == 1 && a.nchunks[1] == 0 && a.prologue != PSSR_PRO_BN_RELU && g_flat_mode) {
+    if (a.taps[0] == 1 && a.nchunks[1] == 0 && a.prologue != PSSR_PRO_BN_RELU && pssr_tunables().igemm_flat) {
         // stage length: 9 chunks unless 4 wastes clearly less of the last stage (K = 64: 4 chunks)
         const int n = a.nchunks[0];
         const bool nine = n > 8 && cdiv(n, 9) * 9 * 100 <= cdiv(n, 4) * 4 * 115;
@@ -1137,7 +1249,7 @@ template <typename T, int BN>
 int launch_geo(const ConvArgs& a, hipStream_t s) {
     const int w = a.W;
     if constexpr (BN == 64 && sizeof(T) == 2) {
-        if (g_big_mode && a.taps[0] == 9 && w >= 16 && a.H >= 16) return launch_t<T, 64, 5, 9>(a, s);
+        if (pssr_tunables().igemm_big && a.taps[0] == 9 && w >= 16 && a.H >= 16) return launch_t<T, 64, 5, 9>(a, s);
     }
     if (w > 8) return launch<T, BN, 0>(a, s);
     if (w > 4) return launch<T, BN, 1>(a, s);
@@ -1149,9 +1261,10 @@ int launch_geo(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 int launch_bn(const ConvArgs& a, hipStream_t s) {
     if (a.cout > 64) {
+        if constexpr (sizeof(T) == 2) { if (use_v3<T>(a)) return launch3_t<T, 128>(a, s); }
         if (use_v2<T, 128>(a)) return a.taps[0] == 9 ? launch2_t<T, 128, 9>(a, s) : launch2_t<T, 128, 1>(a, s);
         if constexpr (sizeof(T) == 2) {
-            if (g_big_mode == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
+            if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
         }
         return launch_geo<T, 128>(a, s);
     }

@@ -8,9 +8,9 @@
 // keeps all of it in accumulators (9 tiles per wave), and walks a strided subset of the pixel
 // tiles; per tile it stages dy (128 px) and the input halo tile once and reuses the halo for the 9
 // taps.  Partial slabs are combined with f32 atomics (one add per element per workgroup).
-#include <stdlib.h>
 
 #include "common.h"
+#include "tunables.h"
 
 namespace {
 
@@ -577,8 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_1x1_kernel(const WgradArg
 template <int GEO> bool wg_lean_ok(const WgradArgs& p) {
     constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
     constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
-    static int lean = -1;
-    if (lean < 0) { const char* e = getenv("PSSR_WGRAD_LEAN"); lean = e ? atoi(e) : 1; }
+    const int lean = pssr_tunables().wgrad_lean;
     const bool full = p.W % TW == 0 && p.H % TH == 0 && p.N % NI == 0;
     const long span_dy = (p.dy_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.dy_cs * 2;
     const long span_in = (p.in_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.in_cs * 2;
@@ -596,8 +595,7 @@ int launch_1x1(WgradArgs p, hipStream_t stream, int* query) {
     const int slabs = p.co_tiles * p.ci_tiles;
     int split;
     if (query != nullptr || p.parts > 0) {
-        static int target = 0;
-        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS_1X1"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+        const int target = pssr_tunables().wgrad_blocks_1x1;
         split = cdiv(target, slabs);
         if (split > p.n_tiles) split = p.n_tiles;
         if (split < 1) split = 1;
@@ -641,8 +639,7 @@ int launch_t(WgradArgs p, hipStream_t stream, int* query) {
         // stream under the backward chain: with 512 workgroups they finished sooner but took more of the chip and twice the
         // slab traffic from the kernels on that chain (measured per step, c2: 768 -> 14.2 ms, 512 -> 13.6, 384 -> 13.5,
         // 256 -> 13.1, 192 -> 13.5, 128 -> 14.0)
-        static int target = 0;
-        if (target == 0) { const char* e = getenv("PSSR_WGRAD_BLOCKS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+        const int target = pssr_tunables().wgrad_blocks;
         split = cdiv(target, slabs);
         if (split > p.n_tiles) split = p.n_tiles;
         if (split < 1) split = 1;
@@ -670,8 +667,7 @@ int launch_t(WgradArgs p, hipStream_t stream, int* query) {
         const bool full = p.W % TW == 0 && p.H % TH == 0 && p.N % NI == 0;
         const long span_dy = (p.dy_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.dy_cs * 2;
         const long span_in = (p.in_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.in_cs * 2;
-        static int lean = -1;
-        if (lean < 0) { const char* e = getenv("PSSR_WGRAD_LEAN"); lean = e ? atoi(e) : 1; }
+        const int lean = pssr_tunables().wgrad_lean;
         if (lean && full && span_dy < (1L << 30) && span_in < (1L << 30)) {
             static bool attr16_done = false;
             if (!attr16_done) {

@@ -6,7 +6,7 @@
 // RDNet (torch.cat of all previous features, _rdnet.py:132-138) is elided by writing every new
 // feature at its channel offset of one buffer per stage.
 #include "common.h"
-#include <cstdlib>
+#include "tunables.h"
 #include <type_traits>
 
 namespace {
@@ -887,7 +887,7 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
     PSSR_CHECK(in && w_packed && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7: bad args");
     CHECK_REF("dwconv7 in", in_cs, in_co, c); CHECK_REF("dwconv7 out", out_cs, out_co, c);
     const long total = (long)n * h * w * (c / 4);
-    static const int tile_mode = [] { const char* e = getenv("PSSR_DWCONV_TILE"); return e ? atoi(e) : 1; }();
+    const int tile_mode = pssr_tunables().dwconv_tile;
     if (w % 8 == 0 && tile_mode && (long)n * ((h + 7) / 8) * ((w + 15) / 16) * ((c + 63) / 64) < (1L << 31)) {
         if (h > 8) { DISPATCH_T(dtype, (launch_dw_tile<T, 16>(in, in_cs, in_co, w_packed, bias, out, out_cs, out_co, n, h, w, c, accumulate, (hipStream_t)s))); }
         else { DISPATCH_T(dtype, (launch_dw_tile<T, 8>(in, in_cs, in_co, w_packed, bias, out, out_cs, out_co, n, h, w, c, accumulate, (hipStream_t)s))); }
@@ -906,7 +906,7 @@ int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, co
 static inline long dw_slab_blocks(int n, int h, int w, int c, long* per_block_out) {
     const int gy = (c / 4 + 31) / 32;
     const long nseg = (long)n * h * (w / 8);
-    static const int target = [] { const char* e = getenv("PSSR_DWWG_BLOCKS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
+    const int target = pssr_tunables().dwwg_blocks;
     long gs = target / gy;
     if (gs > nseg / 4) gs = nseg / 4;
     if (gs < 1) gs = 1;

@@ -1,0 +1,19 @@
+// Kernel-selection tunables of libpssr_mi355.so: one table, initialised once from PSSR_<NAME> environment variables, changed
+// through pssr_set_option() (include/pssr_mi355.h).  Launch paths read the table, never the environment.
+#pragma once
+#include "../../include/pssr_mi355.h"
+
+struct PssrTunables {
+    int igemm_flat;         // 1x1 convolutions through the stage-of-chunks kernel
+    int igemm_big;          // 256-pixel x 64-channel tiles for 3x3 layers >= 16x16 (0 off, 1 Cout <= 64, 2 all)
+    int igemm_v2;           // round-1 pipelined loop (0 off, 1 large layers, 2 whenever the shape allows)
+    int igemm_v3;           // LDS-DMA / counted-wait 3x3 loop for 16-bit layers with > 64 output channels and >= 16x16 images
+    int igemm_ksplit;       // workgroups a split-K launch of the 128-pixel loop aims for
+    int conv_epi8;          // straight-line 8-channel epilogue
+    int wgrad_lean;         // lean-loader weight-gradient kernel
+    int wgrad_blocks;       // partial slabs of a 3x3 weight gradient
+    int wgrad_blocks_1x1;   // ... of a 1x1 weight gradient
+    int dwconv_tile;        // LDS-tiled depthwise 7x7
+    int dwwg_blocks;        // slabs of the depthwise weight gradient
+};
+PssrTunables& pssr_tunables();

@@ -31,13 +31,18 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 2], ids=["default", "pipelined"])
+@pytest.fixture(params=[(0, 1), (2, 0), (0, 0)], ids=["default", "pipelined", "legacy"])
 def pipeline_mode(request):
-    """Run a test under the default kernel selection and with the pipelined 256-pixel main loop forced on."""
+    """Run a test under the default kernel selection (the LDS-DMA v3 loop where it applies), with the round-1 pipelined
+    256-pixel loop forced on, and with both off (the 128-pixel loop everywhere)."""
     from pssr2_amd import _lib as L
-    old = L.lib().pssr_conv2d_pipeline_mode(request.param)
+    v2, v3 = request.param
+    old2 = L.lib().pssr_set_option(b"IGEMM_V2", v2)
+    old3 = L.lib().pssr_set_option(b"IGEMM_V3", v3)
+    assert old2 >= 0 and old3 >= 0
     yield request.param
-    L.lib().pssr_conv2d_pipeline_mode(old if old >= 0 else 0)
+    L.lib().pssr_set_option(b"IGEMM_V2", old2)
+    L.lib().pssr_set_option(b"IGEMM_V3", old3)
 
 
 CASES += [
