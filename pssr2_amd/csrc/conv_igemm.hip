@@ -13,6 +13,11 @@ extern "C" int pssr_conv2d_pipeline_mode(int mode) {
 
 static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* query_ws);
 
+#ifdef PSSR_V3_STAMPS
+static unsigned* g_stamp_buf = nullptr;
+extern "C" void pssr_debug_stamp_buffer(void* p) { g_stamp_buf = (unsigned*)p; }
+#endif
+
 extern "C" int pssr_conv2d(const pssr_conv_desc* d, pssr_stream_t stream) { return conv2d_entry(d, stream, nullptr); }
 
 extern "C" int64_t pssr_conv2d_workspace_bytes(const pssr_conv_desc* d) {
@@ -77,6 +82,11 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     a.epi8 = esz == 2 && d->epilogue != PSSR_EPI_FINAL && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 &&
              (d->epilogue == PSSR_EPI_STORE || (d->aux_coff % 8 == 0 && d->aux_cstride % 8 == 0));
     if (!pssr_tunables().conv_epi8) a.epi8 = 0;
+    a.dbg = pssr_tunables().igemm_dbg;
+    a.stamps = nullptr;
+#ifdef PSSR_V3_STAMPS
+    a.stamps = g_stamp_buf;
+#endif
     long ws_query = 0;
     if (query_ws) { a.ksplit = -1; a.ws = (float*)&ws_query; }
     else { a.ws = (float*)d->workspace; a.ksplit = d->workspace ? (int)(d->workspace_bytes / 1024) : 0; }

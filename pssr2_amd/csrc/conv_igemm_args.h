@@ -19,6 +19,8 @@ struct ConvArgs {
     int in0_blk, out_blk, aux_blk;
     float out_scale, out_shift;
     int epi8;                   // 16-bit, FINAL excluded, cout / strides / offsets multiples of 8: straight-line 8-channel epilogue
+    unsigned* stamps;           // diagnostic build (-DPSSR_V3_STAMPS) only: per-(workgroup, wave) segment cycle sums
+    int dbg;                    // diagnostic bits (tunable IGEMM_DBG; 0 in production): 1 skip the epilogue, 2 skip the multiply
     int ksplit; float* ws;      // split-K: blockIdx.y owns a chunk range, raw accumulators go to ws (single-source convs only)
 };
 

@@ -1141,7 +1141,13 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
 template <typename T>
 bool use_v3(const ConvArgs& a) {
     if constexpr (sizeof(T) != 2) return false;
-    return pssr_tunables().igemm_v3 != 0 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16 && a.prologue != PSSR_PRO_GELU && a.epi != PSSR_EPI_FINAL && a.epi8;
+    const int mode = pssr_tunables().igemm_v3;
+    if (!mode || a.taps[0] != 9 || a.W < 16 || a.H < 16 || a.prologue == PSSR_PRO_GELU || a.epi == PSSR_EPI_FINAL || !a.epi8) return false;
+    if (mode == 2) return true;             // tests: whenever the shape allows
+    // two workgroups per CU cover each other's barriers, pipeline fill and epilogue: with fewer than ~1.5 tiles per CU the
+    // 128-pixel loop (twice the workgroups) measured faster (32^2 x 256 and 16^2 x 512 layers at batch 32: 828 vs 757, 713 vs 643 TFLOP/s)
+    const long blocks = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.N * cdiv(a.cout, 128);
+    return blocks >= 384;
 }
 
 // the pipelined kernel needs >= 16x16 images and enough 256-pixel tiles to fill the chip (PSSR_IGEMM_V2=0 disables it)

@@ -194,6 +194,21 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     }
     const float* const tab_t = tab + half * 2 * EPS;
 
+#ifdef PSSR_V3_STAMPS
+    unsigned long long st_prev = 0;
+    unsigned st_sum[5] = {0, 0, 0, 0, 0};
+#define V3_STAMP(I)                                                                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if ((I) >= 0) st_sum[(I) < 0 ? 0 : (I)] += (unsigned)(t_ - st_prev);                                      \
+        st_prev = t_;                                                                                             \
+    }
+#else
+#define V3_STAMP(I)
+#endif
     u32x4 a_reg[C::A_ITEMS];
     // image k (0 .. nimg-1) is chunk cb + k of source 0, or chunk k - (ce - cb) of source 1
 #define V3_LOAD_A(K)                                                                                              \
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     if (nst > 0) {
         const int ns0 = 3 * (ce - cb);      // stages of source 0
         // ---- prologue: image 0, stages 0 and 1
+        V3_STAMP(-1)
         V3_LOAD_A(0)
         V3_DMA_B(0, 0)
         if (nst > 1) V3_DMA_B(1, 1)
@@ -264,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
         if (ns0 > 1) { V3_END(3); }         // stage 1 is a 3-piece stage: it stays in flight
         else { V3_END(0); }
 
+        V3_STAMP(4)
         unsigned a_cur = a_addr0;           // image of the current chunk
         int s = 0;
         for (int k = 0; k < ce - cb; ++k) {
@@ -272,22 +289,32 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
             // ---- kernel row 0: requests the next image and the weights of row 2 (always a 3-piece stage)
             if (more) V3_LOAD_A(k + 1)
             V3_DMA_B(s + 2, 2)
-            v3_row<T, 0 * 288, 0 * C::B_STAGE>(acc, a_cur, b_addr0);
+            V3_STAMP(0)
+            if (!(p.dbg & 2)) v3_row<T, 0 * 288, 0 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
+            V3_STAMP(1)
             if (more) { V3_END(6); } else { V3_END(3); }
+            V3_STAMP(3)
             ++s;
             // ---- kernel row 1
             if (s + 2 < nst) V3_DMA_B(s + 2, 0)
-            v3_row<T, 1 * 288, 1 * C::B_STAGE>(acc, a_cur, b_addr0);
+            V3_STAMP(0)
+            if (!(p.dbg & 2)) v3_row<T, 1 * 288, 1 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
+            V3_STAMP(1)
             if (more0) { V3_END(3); } else { V3_END(0); }
+            V3_STAMP(3)
             ++s;
             // ---- kernel row 2: commits the next image
             if (s + 2 < nst) V3_DMA_B(s + 2, 1)
-            v3_row<T, 2 * 288, 2 * C::B_STAGE>(acc, a_cur, b_addr0);
+            V3_STAMP(0)
+            if (!(p.dbg & 2)) v3_row<T, 2 * 288, 2 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
+            V3_STAMP(1)
             if (more) V3_COMMIT_A(k + 1)
+            V3_STAMP(2)
             if (more0) { V3_END(3); } else { V3_END(0); }
+            V3_STAMP(3)
             ++s;
             a_cur = a_addr0 + (unsigned)((k + 1) & 1) * C::A_BYTES;
         }
@@ -310,9 +337,20 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
 #undef V3_COMMIT_A
 #undef V3_DMA_B
 #undef V3_END
+#undef V3_STAMP
+#ifdef PSSR_V3_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned* q = p.stamps + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) q[i] = st_sum[i];
+        q[5] = nst;
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        q[6] = xcc; q[7] = (unsigned)(st_prev & 0xffffffffu);
+    }
+#endif
     // the accumulators were last written by MFMAs inside an asm statement: cover their latency before anything reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+    if (p.dbg & 1) return;
     if (p.ksplit > 1) {
         float4* dst = (float4*)p.ws + ((long)blockIdx.x * p.ksplit + blockIdx.y) * (4 * C::MI * C::NJ) * 256 + tid;
 #pragma unroll

@@ -31,9 +31,9 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[(0, 1), (2, 0), (0, 0)], ids=["default", "pipelined", "legacy"])
+@pytest.fixture(params=[(0, 2), (2, 0), (0, 0)], ids=["v3", "pipelined", "legacy"])
 def pipeline_mode(request):
-    """Run a test under the default kernel selection (the LDS-DMA v3 loop where it applies), with the round-1 pipelined
+    """Run a test with the LDS-DMA v3 loop wherever the shape allows, with the round-1 pipelined
     256-pixel loop forced on, and with both off (the 128-pixel loop everywhere)."""
     from pssr2_amd import _lib as L
     v2, v3 = request.param

@@ -58,7 +58,7 @@ def test_v3_forward(case, dt):
     xd = _nhwc(yprev, cin + 16, dt)                 # slice of a wider buffer
     pw = ops.pack_conv_weight(wt.cuda(), code)
     outs = []
-    for on in (1, 0):
+    for on in (2, 0):
         old = _v3(on)
         try:
             out = torch.full((n, h, w, cout + 8), -5.0, dtype=dt, device="cuda")
@@ -100,6 +100,7 @@ def test_v3_dgrad_mask_stats(case, dt):
     mask = (yq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
     gref = torch.where(mask, da, torch.zeros_like(da))
     xd = _nhwc(yprev, cin, dt)
+    old_mode = _v3(2)
     gd = torch.zeros(n, h, w, cin, dtype=dt, device="cuda")
     st2 = torch.zeros(ops.STAT_STRIPES, 2 * cin, dtype=torch.float64, device="cuda")
     pwd = ops.pack_conv_weight(wt.cuda(), code, mode=1)
@@ -123,6 +124,7 @@ def test_v3_dgrad_mask_stats(case, dt):
     ops.conv2d(_nhwc(dy, cout, dt), cout, pwd, g2, cin, n=n, h=h, w=w, x1=_nhwc(dz, cout, dt), cin1=cout,
                w1=ops.pack_conv_weight(w1.cuda(), code, mode=1))
     torch.cuda.synchronize()
+    _v3(old_mode)
     got2 = g2.float().cpu().permute(0, 3, 1, 2)
     np.testing.assert_allclose(got2.numpy(), ref2.numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
 
@@ -131,7 +133,7 @@ def test_options_roundtrip():
     """pssr_set_option / pssr_get_option: the table is the only switch (no launch path reads the environment)."""
     from pssr2_amd import _lib as L
     lib = L.lib()
-    assert lib.pssr_get_option(b"IGEMM_V3") in (0, 1)
+    assert lib.pssr_get_option(b"IGEMM_V3") in (0, 1, 2)
     old = lib.pssr_set_option(b"IGEMM_V3", 0)
     assert lib.pssr_get_option(b"IGEMM_V3") == 0
     assert lib.pssr_set_option(b"IGEMM_V3", old) == 0
