@@ -325,3 +325,88 @@ class DevicePairGenerator:
         from . import ops
         rotations = [False] * len(stacks) if rotations is None else rotations
         return self(ops.gen_pair_geometry_u8(stacks, rotations, hr_res), tile_offset)
+
+
+class DeviceTileDataset(Dataset):
+    """``ArrayDataset`` whose uint8 HR stacks live in HBM: same constructor arguments, same attribute protocol
+    (``val_idx``, ``extra_hr_files``, ``crop_res``, ``lr_scale``, ``is_lr``, ``hr_res``, ``n_frames``, ``_get_name``) and the same
+    ``__getitem__`` contract (float32 CHW tensors, here already on the device), so ``train_paired`` / ``predict_images`` /
+    ``test_metrics`` take it like any dataset.  In addition it can produce whole batches without touching the host
+    (``draw_items`` + ``device_batch``): ``_gen_pair``'s crop / reflect pad / rot90 / flip (host-drawn in the reference's order,
+    applied by one gather kernel), the Pillow-exact reduction and the crappifier (device Philox streams) as HIP launches whose
+    only per-step inputs are device tensors -- which is what lets ``train_paired`` replay a whole training step as one hipGraph
+    (pssr2_amd/fastpath.py).  Noise comes from the device generator: statistically, not bitwise, the numpy stream of the host path."""
+
+    def __init__(self, images, hr_res=512, lr_scale=4, crappifier=Poisson(), val_split=0.1, rotation=True, split_seed=0,
+                 transforms=None, names=None, n_frames=-1, device="cuda", seed=0):
+        if transforms is not None:
+            raise NotImplementedError("DeviceTileDataset applies no host transforms")
+        images = torch.as_tensor(np.asarray(images) if not torch.is_tensor(images) else images)
+        if images.dim() == 3:
+            images = images[:, None]
+        if images.dtype != torch.uint8:
+            raise ValueError("DeviceTileDataset expects uint8 images")
+        self.images = images.to(device).contiguous()
+        lr_scale = None if lr_scale == -1 else lr_scale
+        self.n_frames = _get_n_frames(n_frames)
+        if self.n_frames is not None and self.n_frames[0] != self.n_frames[1]:
+            raise NotImplementedError("DeviceTileDataset: 2.5-D frame slicing (n_frames=[lr, hr]) stays on the host path (ArrayDataset)")
+        n = len(self.images)
+        max_size = max(self.images.shape[-2:])
+        self.val_idx = _get_val_idx([1] * n, val_split, split_seed)
+        self.crop_res = min(hr_res, max_size)
+        self.is_lr = lr_scale is None or max_size <= hr_res // lr_scale
+        self.hr_res, self.lr_scale = hr_res, lr_scale if lr_scale is not None else 1
+        self.crappifier, self.rotation, self.transforms = crappifier, rotation, None
+        self.extra_hr_files = None
+        self.names = names if names is not None else [f"image{i}" for i in range(n)]
+        self._val_set = set(self.val_idx)
+        self.tile_counter = torch.zeros(1, dtype=torch.int64, device=self.images.device)
+        self.gen = DevicePairGenerator(self.lr_scale, crappifier, seed=seed, tile_counter=self.tile_counter)
+        self._item_bytes = 24             # struct pssr_gather_item {src, sh, sw, rot, flip_axis}
+
+    def __len__(self):
+        return len(self.images)
+
+    def _get_name(self, idx):
+        return self.names[idx]
+
+    def _draw_rotation(self, idx):
+        if self.rotation and idx not in self._val_set:
+            return [bool(random.getrandbits(1)), random.choice((1, 2, (1, 2)))]      # the reference's draws, in its order
+        return False
+
+    def draw_items(self, indices):
+        """Gather table (int64 [n, 3] on the device = n ``pssr_gather_item``) for these dataset indices, drawing the training
+        rotations exactly as ``__getitem__`` would for the same sequence of indices."""
+        import struct
+        c, h, w = self.images.shape[1:]
+        base, stride = self.images.data_ptr(), c * h * w
+        buf = bytearray()
+        for i in indices:
+            rot = self._draw_rotation(int(i))
+            axis = -1
+            if rot:
+                axis = 3 if isinstance(rot[1], (tuple, list)) else int(rot[1])
+            buf += struct.pack("<Qiiii", base + int(i) * stride, h, w, int(bool(rot and rot[0])), axis)
+        return torch.frombuffer(buf, dtype=torch.int64).view(-1, 3).to(self.images.device)
+
+    def device_batch(self, items):
+        """items: int64 [b, 3] device rows of ``draw_items``.  Returns float32 (hr, lr) on the device, or lr alone in LR mode.  No
+        host synchronisation, no host-side data: capturable in a hipGraph (the Philox tile counter advances on the device)."""
+        from . import _lib as L, ops
+        b, c = items.shape[0], self.images.shape[1]
+        res = self.hr_res // self.lr_scale if self.is_lr else self.hr_res
+        out = torch.empty(b, c, res, res, dtype=torch.uint8, device=self.images.device)
+        L.check(L.lib().pssr_gen_pair_geometry_u8(L.ptr(items), b, L.ptr(out), c, res, L.stream_ptr()), "pssr_gen_pair_geometry_u8")
+        if self.is_lr:
+            return ops.u8_to_f32(out)
+        hr, lr = self.gen(out)
+        ops.counter_add(self.tile_counter, b)
+        return hr, lr
+
+    def __getitem__(self, idx):
+        if idx >= len(self):
+            raise IndexError(f"Tried to retrieve invalid image. Index {idx} is not less than {len(self)} total image frame slices.")
+        out = self.device_batch(self.draw_items([idx]))
+        return out[0] if self.is_lr else (out[0][0], out[1][0])

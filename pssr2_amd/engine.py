@@ -64,11 +64,15 @@ class _BNState:
 class _Conv:
     """Packed-weight cache of one nn.Conv2d (re-packed only when the parameter version changes)."""
 
-    def __init__(self, module, specs):
+    def __init__(self, module, specs, wepoch=None):
         self.m = module
         self.specs = specs          # name -> dict(mode, ci_begin, ci_count, n_perm, w3x3_from_1x1)
         self.packed = {}
         self.version = {}
+        self.wepoch = wepoch if wepoch is not None else [0]     # Engine._wepoch: bumped when weights changed behind torch's back
+
+    def ver(self):
+        return (self.wepoch[0], self.m.weight._version)
 
     def weight_for(self, spec):
         w = self.m.weight
@@ -95,7 +99,7 @@ class _Conv:
     def get(self, name, dtype):
         spec = self.specs[name]
         key = (name, dtype)
-        ver = self.m.weight._version
+        ver = self.ver()
         if self.version.get(key) != ver or key not in self.packed:
             self.packed[key] = ops.pack_conv_weight(self.weight_for(spec).contiguous(), dtype, mode=spec["mode"],
                                                     ci_begin=spec.get("ci_begin", 0), ci_count=spec.get("ci_count"),
@@ -111,6 +115,7 @@ class Engine:
         self.saved = None
         self._convs = {}
         self.reducer = None          # pssr2_amd.distributed.GradReducer when data-parallel
+        self._wepoch = [0]           # part of every packed-weight / folded-BatchNorm cache key (mark_weights_changed)
         self._flat_grad = None
         # weight-gradient launches (wgrad + partial-slab reduction) on a second HIP stream: nothing on the backward's
         # dependent chain waits for them, so they fill the chip while the chain runs its tiny BatchNorm-coefficient
@@ -120,6 +125,21 @@ class Engine:
         self._side = None
         self._side_on = False
         self._pending = {}
+
+    # ------------------------------------------------------------------ hipGraph replay support (pssr2_amd/fastpath.py)
+    def mark_weights_changed(self):
+        """Parameters or BatchNorm buffers were written without torch noticing (a replayed hipGraph that contains the optimizer
+        step): every packed-weight copy and every folded eval-mode BatchNorm affine is stale from now on."""
+        self._wepoch[0] += 1
+
+    def publish_grads(self):
+        """Point ``.grad`` of every parameter that has none at its slot of the flat gradient buffer (what the end of an eager
+        backward does): a replayed backward graph writes the buffer but runs no Python."""
+        if self._flat_grad is None:
+            return
+        for prm, view in zip(self.model.parameters(), self._gviews):
+            if prm.requires_grad and prm.grad is None:
+                prm.grad = view
 
     # ------------------------------------------------------------------ flat gradient buffer
     def _grad_layout(self, device):
@@ -265,7 +285,7 @@ class Engine:
         """Re-pack every cached conv weight whose parameter changed (an optimizer step changes all of them) with ONE
         launch instead of one per (conv, form).  Entries that were never packed yet stay on the lazy path of _Conv.get."""
         convs = [c for c in self._convs.values() if c.packed]
-        stale = [(c, key) for c in convs for key in c.packed if c.version.get(key) != c.m.weight._version]
+        stale = [(c, key) for c in convs for key in c.packed if c.version.get(key) != c.ver()]
         if len(stale) < 8:
             return
         sig = tuple((id(c), key, c.m.weight.data_ptr(), c.packed[key].data.data_ptr()) for c, key in stale)
@@ -277,12 +297,12 @@ class Engine:
             self._pack_sig = sig
         L.check(L.lib().pssr_pack_conv_weight_batch(L.ptr(self._pack_table), len(stale), L.stream_ptr()), "pssr_pack_conv_weight_batch")
         for c, key in stale:
-            c.version[key] = c.m.weight._version
+            c.version[key] = c.ver()
 
     def _conv(self, module, **specs):
         c = self._convs.get(id(module))
         if c is None:
-            c = self._convs[id(module)] = _Conv(module, specs)
+            c = self._convs[id(module)] = _Conv(module, specs, self._wepoch)
         return c
 
     def _check_supported(self, dtype_code, h, w, train):
@@ -401,7 +421,7 @@ class Engine:
             # through torch (load_state_dict, an optimizer step) or after a training forward (37 five-microsecond launches
             # were 4.6 % of an inference pass)
             ts = (bn_module.weight, bn_module.bias, bn_module.running_mean, bn_module.running_var)
-            key = tuple((t.data_ptr(), t._version) for t in ts)
+            key = (self._wepoch[0],) + tuple((t.data_ptr(), t._version) for t in ts)
             if getattr(st, "eval_key", None) != key:
                 ops.bn_eval_affine(*ts, BN_EPS, st.scale, st.shift)
                 st.eval_key = key

@@ -1,0 +1,239 @@
+"""hipGraph replay behind ``train_paired`` / ``predict_images`` (no reference counterpart: the reference issues every op from Python).
+
+A training step of the MI355X path is 300-700 kernel launches; issued one by one through ctypes they cost more host time
+than the GPU needs to run them (c2: 33 ms vs 13 ms per step).  When the dataset can produce its batches on the device from
+device-resident inputs only (``DeviceTileDataset.device_batch``) nothing that changes from step to step is a kernel
+argument -- the batch's gather table is read through a device cursor, the Philox tile counter, the AdamW step count and the
+learning rate live in HBM -- so the drivers run the first two batches of the first epoch eagerly (real steps: they are also
+the warm-up), capture the third into a ``torch.cuda.CUDAGraph`` and replay it for every further full batch of every epoch.
+Partial last batches, other datasets, ``extra`` losses and unsupported models take the ordinary loop.
+
+What a replay does not do is run Python: with the optimizer inside the graph ``.grad`` is ``None`` between steps, as after the
+reference's ``zero_grad()`` (the captured backward zeroes the engine's flat gradient buffer itself), parameter ``_version``
+counters do not move
+(``Engine.mark_weights_changed`` invalidates the packed-weight caches when control returns to eager code), and a learning-rate
+scheduler reaches the captured optimizer through ``FusedAdamW.sync_device_lr``.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import distributed as D
+
+
+def enabled():
+    return os.environ.get("PSSR_GRAPH", "1") != "0"
+
+
+def supports(model, dataset, device):
+    """The replay path needs an engine-backed model on the GPU and a dataset that batches on the device."""
+    return (enabled() and getattr(model, "_engine", None) is not None and hasattr(dataset, "device_batch") and hasattr(dataset, "draw_items")
+            and torch.device(device).type == "cuda" and getattr(dataset, "extra_hr_files", None) is None)
+
+
+class _Cursor:
+    """Gather table of an epoch (device int64 [n, 3]) read ``batch`` rows at a time through a device-side cursor."""
+
+    def __init__(self, dataset, batch, capacity, device):
+        self.dataset, self.batch = dataset, batch
+        self.table = torch.zeros(max(capacity, batch), 3, dtype=torch.int64, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)
+        self.ar = torch.arange(batch, device=device)
+
+    def load(self, order):
+        rows = self.dataset.draw_items(order)
+        if rows.shape[0] > self.table.shape[0]:
+            raise RuntimeError("epoch longer than the captured gather table")
+        self.table[:rows.shape[0]].copy_(rows)
+        self.cursor.zero_()
+        return rows.shape[0]
+
+    def next_rows(self):
+        rows = self.table[self.ar + self.cursor]
+        self.cursor.add_(self.batch)
+        return rows
+
+    def tail_rows(self, start, count):
+        return self.table[start:start + count]
+
+
+class TrainStepper:
+    """One training step of ``train_paired`` (pssr/train.py:86-103) as a replayed graph."""
+
+    WARM = 2
+
+    def __init__(self, model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, capacity, device):
+        from .optim import FusedAdamW
+        self.model, self.dataset, self.batch, self.loss_fn, self.optim = model, dataset, batch_size, loss_fn, optim
+        self.clamp, self.image_range, self.scaler = clamp, image_range, scaler
+        self.engine = model._engine
+        self.rank, self.world = D.rank_world()
+        self.fused = isinstance(optim, FusedAdamW)
+        self.in_graph_optim = self.fused and self.world == 1 and scaler is None
+        if self.fused:
+            optim.device_state = True
+        self.scale_dev = torch.ones(1, device=device) if scaler is not None else None
+        self.cur = _Cursor(dataset, batch_size, capacity, device)
+        self.graph, self.outs, self.eager_done = None, None, 0
+
+    def begin_epoch(self, order):
+        self.n = self.cur.load(order)
+        self.pos = 0
+        return (self.n + self.batch - 1) // self.batch
+
+    # ---- the step itself (what the slow loop of train_paired does, on device-made batches)
+    def _fwd_bwd(self, rows):
+        hr, lr = self.dataset.device_batch(rows)
+        hr_hat = self.model(lr)
+        if self.clamp:
+            hr_hat = torch.clamp(hr_hat, 0, self.image_range)
+        loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
+        (loss * self.scale_dev if self.scale_dev is not None else loss).backward()
+        return hr, lr, hr_hat, loss
+
+    def _body(self, rows=None):
+        out = self._fwd_bwd(self.cur.next_rows() if rows is None else rows)
+        if self.in_graph_optim:
+            self.optim.step()
+            self.optim.zero_grad()      # Python only (.grad = None): the next backward publishes views of the flat buffer again
+        return out
+
+    def _after(self):
+        """Everything of a step that stays outside the graph: (all-reduce,) optimizer, zero_grad -- the reference's order."""
+        eng, opt = self.engine, self.optim
+        if self.in_graph_optim:
+            return
+        if self.world > 1:
+            torch.distributed.all_reduce(eng._flat_grad)
+        eng.publish_grads()             # a replayed backward wrote the flat buffer but ran no Python
+        if self.scaler is not None:
+            if self.world > 1:
+                eng._flat_grad.mul_(1.0 / self.world)
+            self.scaler.step(opt, list(self.model.parameters()))
+            self.scale_dev.fill_(self.scaler.scale_value)
+        elif self.fused:
+            opt.step(grad_scale=1.0 / self.world)
+        else:
+            if self.world > 1:
+                eng._flat_grad.mul_(1.0 / self.world)
+            opt.step()
+        opt.zero_grad()
+
+    def step(self):
+        """Next batch of the epoch.  Returns (hr, lr, hr_hat, loss) device tensors (static buffers once the graph is captured)."""
+        left = self.n - self.pos
+        if left < self.batch:                               # partial last batch: ordinary launches, its own engine plan
+            self._leave_graph()
+            out = self._body(self.cur.tail_rows(self.pos, left))
+            self._after()
+            self.pos += left
+            self._leave_graph()
+            return out
+        self.pos += self.batch
+        if self.graph is None and self.eager_done < self.WARM:
+            if self.scaler is not None:
+                self.scale_dev.fill_(self.scaler.scale_value)
+            out = self._body()                              # real steps that double as warm-up (weights end up stale: the capture
+            self._after()                                   # below then contains the packed-weight refresh)
+            self.eager_done += 1
+            return out
+        if self.graph is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.outs = self._body()
+            self.graph = g
+        self.graph.replay()
+        self._after()
+        return self.outs
+
+    def _leave_graph(self):
+        """Control goes back to eager code (or to another graph): its caches must not trust parameter versions."""
+        self.engine.mark_weights_changed()
+
+    def finish(self):
+        self._leave_graph()
+
+
+class EvalStepper:
+    """No-grad forward (+ loss) over device-made batches as a replayed graph: the validation loop of ``train_paired``
+    (pssr/train.py:122-148) and the prediction loop of ``predict_images`` (pssr/predict.py:52-60)."""
+
+    def __init__(self, model, dataset, batch_size, device, loss_fn=None, clamp=False, image_range=255, to_u8=False, weights_move=True):
+        self.model, self.dataset, self.batch, self.loss_fn = model, dataset, batch_size, loss_fn
+        self.clamp, self.image_range, self.to_u8 = clamp, image_range, to_u8
+        self.engine = model._engine
+        self.weights_move = weights_move           # True: the weights change between uses (validation inside training)
+        self.cur = _Cursor(dataset, batch_size, max(len(dataset.val_idx), batch_size), device)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
+        self.graph, self.outs, self.eager_done = None, None, 0
+        self.sig = None
+
+    def _signature(self):
+        """Everything a captured eval forward depends on besides its inputs (weights_move = False: the graph holds no
+        packed-weight refresh, so a change has to be seen here and answered by one eager batch, which refreshes the shared buffers)."""
+        m = self.model
+        return (self.engine._wepoch[0], tuple(p._version for p in m.parameters()), tuple(b._version for b in m.buffers()))
+
+    def begin(self, order):
+        self.n = self.cur.load(order)
+        self.pos = 0
+        self.loss_sum.zero_()
+        self.count = 0
+        if self.weights_move:
+            self.engine.mark_weights_changed()
+        elif self._signature() != self.sig:
+            self.eager_done = 0             # the first full batch of this pass runs eagerly: packed weights / folded BatchNorm are refreshed
+        return (self.n + self.batch - 1) // self.batch
+
+    def _run(self, rows):
+        from . import ops
+        with torch.no_grad():
+            item = self.dataset.device_batch(rows)
+            hr, lr = (None, item) if self.dataset.is_lr else item
+            hr_hat = self.model(lr)
+            if self.clamp:
+                hr_hat = torch.clamp(hr_hat, 0, self.image_range)
+            loss = None
+            if self.loss_fn is not None:
+                loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
+                self.loss_sum.add_(loss.detach().float().reshape(1))
+            u8 = None
+            if self.to_u8:
+                y = hr_hat.detach().contiguous().float()
+                u8 = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
+                ops.clip_u8(y, u8)
+        return hr, lr, hr_hat, loss, u8
+
+    def step(self):
+        left = self.n - self.pos
+        if left < self.batch:
+            if self.weights_move:
+                self.engine.mark_weights_changed()
+            out = self._run(self.cur.tail_rows(self.pos, left))
+            self.pos += left
+            self.count += 1
+            return out
+        self.pos += self.batch
+        self.count += 1
+        if self.eager_done < 1:
+            self.eager_done += 1
+            out = self._run(self.cur.next_rows())
+            self.sig = self._signature()
+            return out
+        if self.graph is None:
+            torch.cuda.synchronize()
+            if self.weights_move:
+                self.engine.mark_weights_changed()          # capture the packed-weight refresh and the BatchNorm folds too
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.outs = self._run(self.cur.next_rows())
+            self.graph = g
+        self.graph.replay()
+        return self.outs
+
+    def mean_loss_stat(self):
+        """[sum of batch losses, number of batches] on the device."""
+        return torch.stack([self.loss_sum[0], torch.tensor(float(self.count), device=self.loss_sum.device)])

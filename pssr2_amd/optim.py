@@ -82,6 +82,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 torch.autograd.graph.increment_version(p)
         return loss
 
+    def sync_device_lr(self):
+        """Write the groups' current learning rates to the device-side state (``device_state`` mode): a replayed hipGraph reads
+        the rate from HBM, so a scheduler's change has to be pushed there (pssr2_amd/fastpath.py)."""
+        import struct
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            if st is not None and "dev" in st and st.get("dev_lr") != group["lr"]:
+                st["dev"][1] = struct.unpack("<I", struct.pack("<f", float(group["lr"])))[0]
+                st["dev_lr"] = group["lr"]
+
     def flat_grad(self, gi=0):
         """Flat gradient buffer of a group (the engine writes into it directly when it can)."""
         st = self._flat.get(gi)

@@ -271,7 +271,7 @@ class RDEngine(Engine):
         """Packed weight of a conv module under a named packing spec (cached per parameter version)."""
         c = self._convs.get(id(module))
         if c is None:
-            c = self._convs[id(module)] = _Conv(module, {})
+            c = self._convs[id(module)] = _Conv(module, {}, self._wepoch)
         if name not in c.specs:
             c.specs[name] = spec
         return c.get(name, code)

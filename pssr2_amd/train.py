@@ -57,15 +57,22 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
     train_idx = _invert_idx(dataset.val_idx, len(dataset))
     train_sampler = _RandomIterIdx(train_idx, rank=rank, world=world, shuffle_seed=0 if world > 1 else None)
     val_sampler = _RandomIterIdx(dataset.val_idx, seed=True, rank=rank, world=world)
-    train_dataloader = DataLoader(dataset, batch_size, sampler=train_sampler, **dataloader_kwargs)
-    val_dataloader = DataLoader(dataset, batch_size, sampler=val_sampler, **dataloader_kwargs)
     include_metric = type(scheduler) == torch.optim.lr_scheduler.ReduceLROnPlateau
 
     model.to(device)
     engine = getattr(model, "_engine", None)
+    # hipGraph replay of whole steps when the dataset makes its batches on the device (pssr2_amd/fastpath.py); everything else
+    # (host datasets, DataLoader workers, user crappifier subclasses, ``extra`` losses) takes the reference's loop below
+    from . import fastpath
+    fast = fastpath.supports(model, dataset, device) and not dataloader_kwargs
+    if fast:
+        train_dataloader = val_dataloader = None
+    else:
+        train_dataloader = DataLoader(dataset, batch_size, sampler=train_sampler, **dataloader_kwargs)
+        val_dataloader = DataLoader(dataset, batch_size, sampler=val_sampler, **dataloader_kwargs)
     if world > 1:
         D.broadcast_module(model)
-        if engine is not None and engine.reducer is None:
+        if engine is not None and engine.reducer is None and not fast:
             engine.attach_reducer()
 
     # fp16 storage (model.compute_dtype = torch.float16) needs loss scaling; f32 / bf16 do not
@@ -74,33 +81,44 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
         from .optim import LossScaler
         scaler = LossScaler()
 
+    stepper = evaler = None
+    if fast:
+        stepper = fastpath.TrainStepper(model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, len(train_sampler), device)
+        evaler = fastpath.EvalStepper(model, dataset, batch_size, device, loss_fn=loss_fn, clamp=clamp, image_range=image_range)
+
     train_losses, val_losses = [], []
     for epoch in range(epochs):
         model.train()
         if rank == 0:
             print(f"Epoch {epoch}:")
-        progress = tqdm(train_dataloader, disable=rank != 0)
+        if fast:
+            progress = tqdm(range(stepper.begin_epoch(list(train_sampler))), disable=rank != 0)
+        else:
+            progress = tqdm(train_dataloader, disable=rank != 0)
         for batch_idx, data in enumerate(progress):
-            if dataset.extra_hr_files is None:
-                hr, lr = data
+            if fast:
+                hr, lr, hr_hat, loss = stepper.step()
             else:
-                (hr, lr), extra = data
-                extra = extra.to(device)
-            hr, lr = hr.to(device), lr.to(device)
+                if dataset.extra_hr_files is None:
+                    hr, lr = data
+                else:
+                    (hr, lr), extra = data
+                    extra = extra.to(device)
+                hr, lr = hr.to(device), lr.to(device)
 
-            hr_hat = model(lr)
-            if clamp:
-                hr_hat = torch.clamp(hr_hat, 0, image_range)
-            loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
-                else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
-            (scaler.scale(loss) if scaler is not None else loss).backward()
-            if world > 1 and engine is None:
-                D.allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
-            if scaler is not None:
-                scaler.step(optim, list(model.parameters()))
-            else:
-                optim.step()
-            optim.zero_grad()
+                hr_hat = model(lr)
+                if clamp:
+                    hr_hat = torch.clamp(hr_hat, 0, image_range)
+                loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
+                    else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
+                (scaler.scale(loss) if scaler is not None else loss).backward()
+                if world > 1 and engine is None:
+                    D.allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
+                if scaler is not None:
+                    scaler.step(optim, list(model.parameters()))
+                else:
+                    optim.step()
+                optim.zero_grad()
 
             if batch_idx % log_frequency == 0 or batch_idx == len(progress) - 1:
                 train_losses.append(loss.item())
@@ -112,30 +130,42 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
                 last_full = [lr.cpu(), hr_hat.detach().cpu(), hr.cpu()]       # accessible from callbacks via locals
             for idx, callback in enumerate(callbacks):
                 callback(locals()) if callback_locals[idx] else callback()
+        if fast:
+            stepper.finish()
 
         model.eval()
         if rank == 0:
             print(f"Epoch {epoch} validation...")
         val_loss = []
-        progress = tqdm(val_dataloader, disable=rank != 0)
+        if fast:
+            progress = tqdm(range(evaler.begin(list(val_sampler))), disable=rank != 0)
+        else:
+            progress = tqdm(val_dataloader, disable=rank != 0)
         with torch.no_grad():
             for batch_idx, data in enumerate(progress):
-                if dataset.extra_hr_files is None:
-                    hr, lr = data
+                if fast:
+                    hr, lr, hr_hat, loss, _ = evaler.step()
                 else:
-                    (hr, lr), extra = data
-                    extra = extra.to(device)
-                hr, lr = hr.to(device), lr.to(device)
-                hr_hat = model(lr)
-                if clamp:
-                    hr_hat = torch.clamp(hr_hat, 0, image_range)
-                loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
-                    else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
-                val_loss.append(loss.detach().float().reshape(1))            # stays on device: one sync per epoch
+                    if dataset.extra_hr_files is None:
+                        hr, lr = data
+                    else:
+                        (hr, lr), extra = data
+                        extra = extra.to(device)
+                    hr, lr = hr.to(device), lr.to(device)
+                    hr_hat = model(lr)
+                    if clamp:
+                        hr_hat = torch.clamp(hr_hat, 0, image_range)
+                    loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
+                        else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
+                    val_loss.append(loss.detach().float().reshape(1))            # stays on device: one sync per epoch
                 if batch_idx == max(len(progress), 2) - 2:
                     last_full_val = [lr.cpu(), hr_hat.cpu(), hr.cpu()]
-        stat = torch.stack([torch.cat(val_loss).sum(), torch.tensor(float(len(val_loss)), device=val_loss[0].device)]) \
-            if val_loss else torch.zeros(2, device=device)
+        if fast:
+            stat = evaler.mean_loss_stat()
+            engine.mark_weights_changed()
+        else:
+            stat = torch.stack([torch.cat(val_loss).sum(), torch.tensor(float(len(val_loss)), device=val_loss[0].device)]) \
+                if val_loss else torch.zeros(2, device=device)
         if world > 1:
             torch.distributed.all_reduce(stat)
         val_loss = (stat[0] / stat[1].clamp(min=1)).item()
@@ -151,5 +181,7 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
             _collage(*last_full_val, crop_res=dataset.crop_res, lr_scale=dataset.lr_scale).save(f"{collage_dir}/epoch{epoch}_loss{val_loss:.4f}.png")
         if scheduler:
             scheduler.step(val_loss) if include_metric else scheduler.step()
+            if hasattr(optim, "sync_device_lr"):
+                optim.sync_device_lr()
 
     return train_losses, val_losses

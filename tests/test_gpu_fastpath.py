@@ -1,0 +1,159 @@
+"""hipGraph replay inside the drivers (pssr2_amd/fastpath.py): ``train_paired`` / ``predict_images`` on a device-resident dataset
+give what the ordinary launch-by-launch loop gives, and the reference's own 2-epoch trace (tests/golden/train_trace.npz, written by
+oracle/gen_golden.py from pssr/train.py:19-166) is reproduced by ``pssr2_amd.train.train_paired``."""
+import os
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def test_train_paired_reproduces_the_reference_trace():
+    """Same data, initial weights, seeds, loss (MSELoss), optimizer (torch AdamW) and arguments as the reference run that wrote the
+    fixture: the returned loss lists (one entry per batch at log_frequency=1, one validation loss per epoch) and the final weights
+    pin step order (backward -> step -> zero_grad), train/eval toggling, the shuffle stream and the log cadence."""
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.train import train_paired
+    d = np.load(GOLD / "train_trace.npz")
+    hrs, lrs = d["hrs"], d["lrs"]
+
+    class DS(torch.utils.data.Dataset):
+        val_idx, extra_hr_files, crop_res, lr_scale = [4, 5], None, 32, 4
+
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return torch.tensor(hrs[i]), torch.tensor(lrs[i])
+
+    model = ResUNet(hidden=[8, 16], depth=1)
+    model.load_state_dict({k[4:]: torch.from_numpy(np.asarray(d[k])) for k in d.files if k.startswith("sd0/")})
+    model.compute_dtype = torch.float32
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    random.seed(6)
+    tl, vl = train_paired(model, DS(), 2, torch.nn.MSELoss(), opt, epochs=2, device="cuda", log_frequency=1)
+    assert len(tl) == len(d["train_losses"]) == 4 and len(vl) == len(d["val_losses"]) == 2
+    np.testing.assert_allclose(tl, d["train_losses"], rtol=1e-4)
+    np.testing.assert_allclose(vl, d["val_losses"], rtol=1e-4)
+    sd1 = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    worst = 0.0
+    for k in d.files:
+        if not k.startswith("sd1/"):
+            continue
+        name, ref = k[4:], np.asarray(d[k])
+        if name.endswith("num_batches_tracked"):
+            assert int(sd1[name]) == int(ref) == 4
+            continue
+        # A conv bias in front of a batch-statistics BatchNorm has an exactly zero gradient; the reference's autograd leaves round-off
+        # there (~1e-9) which Adam normalises to a full +-lr step, the engine leaves the slot zero: those biases move by up to
+        # 4 * lr in the reference and only by weight decay here, with no effect on any output (BatchNorm removes them).
+        parts = name.split(".")
+        if parts[-1] == "bias" and "conv" in parts and parts[parts.index("conv") + 1] in ("0", "3"):
+            continue
+        err = float(np.abs(sd1[name] - ref).max())
+        worst = max(worst, err)
+        np.testing.assert_allclose(sd1[name], ref, rtol=2e-3, atol=2e-4, err_msg=name)
+    print(f"train trace: max |weight - reference| after 4 AdamW steps = {worst:.2e}")
+
+
+def _tiles(n, res, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(n, 1, res // 4, res // 4)).astype(np.float32)
+    up = np.kron(base, np.ones((1, 1, 4, 4), dtype=np.float32)) + rng.normal(0, 6, size=(n, 1, res, res))
+    return np.clip(up, 0, 255).astype(np.uint8)
+
+
+def _run_train(graph, fused, epochs=2, n=44, batch=8, dtype=torch.float32, scheduler=False):
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    os.environ["PSSR_GRAPH"] = "1" if graph else "0"
+    try:
+        torch.manual_seed(3)
+        random.seed(11)
+        model = ResUNet(hidden=[16, 32], depth=1).cuda()
+        model.compute_dtype = dtype
+        ds = DeviceTileDataset(_tiles(n, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.2, rotation=True,
+                               device="cuda", seed=21)
+        # eps = 1e-3: with the default 1e-8 Adam turns round-off in a near-zero gradient into a full +-lr step, and the last-ulp difference
+        # between the host's and the device's bias correction (FusedAdamW.device_state) grows to 5e-4 in the loss within six steps
+        opt = (FusedAdamW if fused else torch.optim.AdamW)(model.parameters(), lr=2e-3, eps=1e-3)
+        sch = torch.optim.lr_scheduler.StepLR(opt, 1, 0.5) if scheduler else None
+        seen = []
+
+        def cb(loc):
+            seen.append((loc["batch_idx"], tuple(loc["hr_hat"].shape), float(loc["loss"].detach())))
+        tl, vl = train_paired(model, ds, batch, SSIMLoss(ms=False, win_size=7), opt, epochs, device="cuda", scheduler=sch, log_frequency=2,
+                              callbacks=[cb])
+        return tl, vl, {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, seen
+    finally:
+        os.environ.pop("PSSR_GRAPH", None)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["FusedAdamW-in-graph", "torch-AdamW-outside"])
+def test_train_paired_graph_equals_eager(fused):
+    """36 training tiles in batches of 8 (4 full batches: 2 eager, 1 captured, 1 replayed; then a partial batch of 4), 8 validation
+    tiles, 2 epochs with a learning-rate scheduler: losses, callback view and final weights equal the launch-by-launch loop's."""
+    a = _run_train(True, fused, scheduler=True)
+    b = _run_train(False, fused, scheduler=True)
+    assert len(a[0]) == len(b[0]) and len(a[1]) == len(b[1]) == 2
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-6)
+    assert [s[:2] for s in a[3]] == [s[:2] for s in b[3]] and len(a[3]) == 10        # 5 batches per epoch, the last of 4 tiles
+    assert a[3][4][1][0] == 4
+    np.testing.assert_allclose([s[2] for s in a[3]], [s[2] for s in b[3]], rtol=2e-6)
+    for k in a[2]:
+        if "num_batches_tracked" in k:
+            assert int(a[2][k]) == int(b[2][k]) == 10
+            continue
+        parts = k.split(".")
+        if parts[-1] == "bias" and "conv" in parts and parts[parts.index("conv") + 1] in ("0", "3"):
+            continue        # exact-zero gradient in front of BatchNorm (see the trace test)
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_predict_images_graph_equals_eager():
+    """Inference is deterministic: the replayed graph gives the eager loop's uint8 predictions bit for bit, on the host dict, on the
+    device dict (``device_outputs``) and on a second call that only replays (weights changed in between: refreshed by one eager batch)."""
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images
+    torch.manual_seed(4)
+    model = ResUNet(hidden=[16, 32], depth=1).cuda()
+    model.compute_dtype = torch.bfloat16
+    tiles = _tiles(27, 64, seed=5)
+    ds = DeviceTileDataset(tiles, hr_res=64, lr_scale=4, crappifier=None, val_split=1.0, rotation=False, device="cuda")
+    os.environ["PSSR_GRAPH"] = "0"
+    try:
+        ref = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    finally:
+        os.environ.pop("PSSR_GRAPH", None)
+    got = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    assert list(got) == list(ref) == [f"image{i}" for i in range(27)]
+    for k in ref:
+        assert got[k].dtype == np.uint8 and got[k].shape == (1, 64, 64) and np.array_equal(got[k], ref[k]), k
+    ds.device_outputs = True
+    dev = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    for k in ref:
+        assert dev[k].is_cuda and np.array_equal(dev[k].cpu().numpy(), ref[k]), k
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+    os.environ["PSSR_GRAPH"] = "0"
+    try:
+        ds.device_outputs = False
+        ref2 = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    finally:
+        os.environ.pop("PSSR_GRAPH", None)
+    got2 = predict_images(model, ds, device="cuda", batch_size=6, out_dir=None)
+    assert any(not np.array_equal(ref2[k], ref[k]) for k in ref)
+    for k in ref2:
+        assert np.array_equal(got2[k], ref2[k]), k
