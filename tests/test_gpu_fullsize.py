@@ -23,7 +23,7 @@ def _psnr(a, b):
 def test_config_c2_c3_eval_properties(family):
     """128^2 -> 512^2, batch 32 (configs 2 / 3): same bits on a re-run; a batch of 32 equals its two halves of 16 up to the
     summation order of the deepest layers (no statistic crosses tiles in eval mode; the smaller batch takes split-K there:
-    > 60 dB apart); bf16 storage stays within 0.05 dB of the exact-f32 build on PSNR against a fixed target."""
+    > 60 dB apart); bf16 storage stays within 1e-3 dB of the exact-f32 build (measured: printed) on PSNR against a fixed target."""
     from pssr2_amd.models import RDResUNet, ResUNet
     cls = ResUNet if family == "resunet" else RDResUNet
     model = _model(cls, torch.bfloat16).eval()
@@ -38,7 +38,9 @@ def test_config_c2_c3_eval_properties(family):
         model.compute_dtype = torch.float32
         y32 = model(x[:8]).clone()
     target = (torch.rand(8, 1, 512, 512, generator=g) * 255).cuda()
-    assert abs(_psnr(y[:8], target) - _psnr(y32, target)) < 0.05
+    dpsnr = abs(_psnr(y[:8], target) - _psnr(y32, target))
+    print(f"[{family} c2/c3 shape, untrained] |PSNR_bf16 - PSNR_f32| vs a fixed target = {dpsnr:.2e} dB; PSNR(bf16 output | f32 output) = {_psnr(y[:8], y32):.1f} dB")
+    assert dpsnr < 1e-3      # measured 3e-5 (ResUNet) / 7e-6 (RDResUNet)
     assert _psnr(y[:8], y32) > 35.0
 
 

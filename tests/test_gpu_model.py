@@ -137,7 +137,9 @@ def test_bf16_close_to_f32(golden):
     target = torch.tensor(g["tiny_target"])
     rel = (y - ref).abs().max() / ref.abs().max()
     assert rel < 0.05, rel
-    assert abs(_psnr(y, target) - _psnr(ref, target)) < 0.05     # bf16 storage: looser than the f32 criterion
+    dpsnr = abs(_psnr(y, target) - _psnr(ref, target))
+    print(f"[bf16 vs reference fixture, untrained tiny net] max rel {float(rel):.2e}, |dPSNR| {dpsnr:.2e} dB")
+    assert dpsnr < 1e-3     # the north-star criterion itself; measured 9e-5 here, 7e-4 on trained weights (tests/test_gpu_parity_trained.py)
     model.train()
     out = model(x)
     loss = torch.nn.functional.mse_loss(out / 255, target.cuda() / 255)

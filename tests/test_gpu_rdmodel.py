@@ -138,7 +138,9 @@ def test_bf16_vs_oracle():
         y = model(x.cuda()).cpu()
         ref, _ = R.rdresunet_forward(x, sd0, cfg, train=False)
     assert (y - ref).abs().max() / ref.abs().max() < 0.05
-    assert abs(_psnr(y, target) - _psnr(ref, target)) < 0.05
+    dpsnr = abs(_psnr(y, target) - _psnr(ref, target))
+    print(f"[RDResUNet bf16 vs f32 oracle, untrained] |dPSNR| {dpsnr:.2e} dB")
+    assert dpsnr < 1e-3      # measured 3e-5
     model.train()
     out = model(x.cuda())
     torch.nn.functional.mse_loss(out / 255, target.cuda() / 255).backward()
