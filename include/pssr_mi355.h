@@ -331,6 +331,53 @@ int pssr_gen_pair_geometry_u8(const pssr_gather_item* items_dev, int n_items, ui
 
 
 /* ---------------------------------------------------------------------------------------------
+ * Atrous / PSP-pooling model variants (pssr/models/_blocks.py:43-92 ResBlockA, PSP_Pooling).
+ * A dilated 3x3 convolution (Conv2d(kernel_size=3, padding="same", dilation=d), _blocks.py:55) = pssr_im2col_dil + the 1x1
+ * kernels of pssr_conv2d / pssr_conv2d_wgrad over K = 9 * cp (weights packed with mode 4; mode 5 for the input gradient) +
+ * pssr_col2im_dil.  Tensors are NHWC slices (pointer, channel stride, channel offset) in the compute dtype.
+ */
+/* out[n, y, x, ci] = x_nchw * pre_scale + pre_shift (ci < c), 0 for c <= ci < out_cs: the network input "x / 128 - 1"
+ * (resunet.py:66) of the atrous models, which have no input BatchNorm (resunet.py:50) */
+int pssr_input_plain(const float* x_nchw, void* out, int n, int c, int h, int w, int out_cs, float pre_scale, float pre_shift,
+                     int dtype, pssr_stream_t stream);
+/* col[pixel][t * cp + ci] = act(in[pixel + ((t / 3 - 1) * dil, (t % 3 - 1) * dil)][ci]), zero outside the image and for
+ * c <= ci < cp; act = relu(v * scale[ci] + shift[ci]) rounded to the compute dtype (the pre-activation BatchNorm + ReLU of
+ * ResBlockA, _blocks.py:52-55) or the identity when scale == shift == NULL.  col: [n][h][w][9 * cp]. */
+int pssr_im2col_dil(const void* in, int in_cs, int in_co, int c, const float* scale, const float* shift, void* col, int cp,
+                    int n, int h, int w, int dil, int dtype, pssr_stream_t stream);
+/* Gradient of the above: out[pixel][ci] = sum_t dcol[pixel - off_t][t * cp + ci].  With y != NULL the ReLU mask of the
+ * pre-activation (y * scale + shift > 0) is applied; with stats != NULL also stats[stripe][0:c] += sum g,
+ * stats[stripe][c:2c] += sum g * (y - mean) * invstd (f64, PSSR_STAT_STRIPES stripes, caller-zeroed): the inputs of
+ * pssr_bn_bwd_coefs for the BatchNorm in front of the ReLU. */
+int pssr_col2im_dil(const void* dcol, int cp, void* out, int out_cs, int out_co, int c, int n, int h, int w, int dil,
+                    const void* y, int y_cs, int y_co, const float* scale, const float* shift, const float* mean,
+                    const float* invstd, double* stats, int dtype, pssr_stream_t stream);
+/* stats[stripe][0:c] += sum x, stats[stripe][c:2c] += sum x^2 over the pixels of an NHWC slice: batch statistics of a
+ * BatchNorm that normalises an existing tensor (the first BatchNorm of every ResBlockA branch, the BatchNorms of PSP_Pooling) */
+int pssr_channel_stats_nhwc(const void* x, int cs, int co, int c, int64_t npix, double* stats, int dtype, pssr_stream_t stream);
+/* out = sum of n_in (1..8) NHWC slices, then ReLU if relu != 0: "relu(sum(branches) + respass)" (_blocks.py:67).  ins / in_cs /
+ * in_co are HOST arrays. */
+int pssr_sum_relu(const void* const* ins, const int* in_cs, const int* in_co, int n_in, void* out, int out_cs, int out_co,
+                  int64_t npix, int c, int relu, int dtype, pssr_stream_t stream);
+/* dz = dout where out > 0 else 0 (gradient of a ReLU from its output) */
+int pssr_relu_mask(const void* dout, int do_cs, int do_co, const void* out, int o_cs, int o_co, void* dz, int dz_cs, int dz_co,
+                   int64_t npix, int c, int dtype, pssr_stream_t stream);
+/* out = relu(x * scale[c] + shift[c]): F.relu(BatchNorm(x)) of PSP_Pooling (_blocks.py:88,91) */
+int pssr_affine_relu(const void* x, int cs, int co, const float* scale, const float* shift, void* out, int out_cs, int out_co,
+                     int64_t npix, int c, int dtype, pssr_stream_t stream);
+/* F.max_pool2d(x, kernel_size=k) (_blocks.py:87; floor mode: out is [n][h / k][w / k][c]) and its gradient (to the first
+ * maximum of each window in row-major order, zero for pixels outside every window) */
+int pssr_maxpool_k(const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co, int n, int h, int w, int c, int k,
+                   int dtype, pssr_stream_t stream);
+int pssr_maxpool_k_bwd(const void* act, int act_cs, int act_co, const void* dpool, int dp_cs, int dp_co, void* dx, int dx_cs,
+                       int dx_co, int n, int h, int w, int c, int k, int dtype, pssr_stream_t stream);
+/* F.interpolate(x, size=(h, w), mode="bilinear") (align_corners=False, _blocks.py:87) from [n][hs][ws][c] and its gradient */
+int pssr_bilinear_up(const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co, int n, int hs, int ws, int h, int w,
+                     int c, int dtype, pssr_stream_t stream);
+int pssr_bilinear_up_bwd(const void* dout, int do_cs, int do_co, void* din, int di_cs, int di_co, int n, int hs, int ws, int h,
+                         int w, int c, int dtype, pssr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * RDNet encoder of RDResUNet (pssr/models/_rdnet.py, pssr/models/rdresunet.py:84).  The 1x1 convolutions of its
  * blocks and transitions run on pssr_conv2d / pssr_conv2d_wgrad (taps = 1; PSSR_PRO_GELU / PSSR_EPI_DGRAD_GELU fuse
  * nn.GELU); the kernels below are the HBM-bound remainder.  torch.cat of the dense features (_rdnet.py:132-138,

@@ -346,6 +346,90 @@ def gen_metrics(pssr):
     np.savez_compressed(OUT / "metrics.npz", **out)
 
 
+ATROUS_CFGS = {
+    # name: (model family, constructor kwargs, input hw, batch)
+    "atrous": ("resunet", dict(channels=1, hidden=[16, 32, 64], scale=4, depth=1, dilations=[[1, 3], [1, 2], [1]]), 32, 2),
+    "psp": ("resunet", dict(channels=1, hidden=[48, 96], scale=4, depth=1, pool_sizes=[1, 2, 4], encoder_pool=False), 24, 2),
+    "psp_enc": ("resunet", dict(channels=[3, 1], hidden=[32, 64], scale=2, depth=0, pool_sizes=[1, 2], encoder_pool=True), 16, 3),
+    "atrous_psp": ("resunet", dict(channels=1, hidden=[32, 64], scale=4, depth=2, dilations=[[1, 5], [2]], pool_sizes=[1, 2], encoder_pool=True), 32, 1),
+    "rd_atrous_psp": ("rdresunet", dict(channels=1, hidden=[32, 64], scale=2, depth=1, dilations=[[1], [1, 3]], pool_sizes=[1, 2], encoder_pool=True,
+                                        rdnet_init=16, growth_rates=[8, 8, 16], ds_blocks=[False, False, True], ese_blocks=[True, False, True],
+                                        n_blocks=[1, 2, 1]), 32, 2),
+}
+
+
+def gen_atrous(pssr):
+    """Atrous / PSP-pooling variants: the reference's ResBlockA and PSP_Pooling on their own, and whole models
+    (ResUNet with dilations / pool_sizes / encoder_pool, RDResUNet with all three): eval / train outputs, running statistics and
+    every parameter gradient of an MSE loss."""
+    from pssr.models._blocks import PSP_Pooling, ResBlockA
+    from pssr.models.rdresunet import RDResUNet
+    from pssr.models.resunet import ResUNet
+    out = {}
+    for name, (family, kw, hw, n) in ATROUS_CFGS.items():
+        torch.manual_seed(13)
+        model = (ResUNet if family == "resunet" else RDResUNet)(**kw)
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+                    m.running_mean.uniform_(-0.1, 0.1), m.running_var.uniform_(0.5, 1.5)
+            for k, prm in model.named_parameters():
+                if k.endswith("gamma"):        # layer scale of the dense blocks (1e-6 at init hides them numerically)
+                    prm.uniform_(0.5, 1.5)
+        ch = kw["channels"]
+        cin = ch[0] if isinstance(ch, list) else ch
+        x = torch.rand(n, cin, hw, hw) * 255
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            y_eval = model(x)
+        model.train()
+        y_train = model(x)
+        target = torch.rand_like(y_train) * 255
+        loss = torch.nn.functional.mse_loss(y_train / 255, target / 255)
+        loss.backward()
+        out[f"{name}_x"], out[f"{name}_target"] = x.numpy(), target.numpy()
+        out[f"{name}_y_eval"], out[f"{name}_y_train"], out[f"{name}_loss"] = y_eval.numpy(), y_train.detach().numpy(), np.array(loss.item())
+        for k, v in sd0.items():
+            out[f"{name}_sd/{k}"] = v.numpy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"{name}_sd_after/{k}"] = v.numpy()
+        for k, prm in model.named_parameters():
+            out[f"{name}_grad/{k}"] = prm.grad.numpy()
+    # per-block fixtures (train mode)
+    torch.manual_seed(4)
+    rb = ResBlockA(8, 16, [1, 3], 1).train()
+    x = torch.randn(2, 8, 12, 12, requires_grad=True)
+    y = rb(x)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    out["resblocka_x"], out["resblocka_y"], out["resblocka_gy"], out["resblocka_dx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    for k, v in rb.state_dict().items():
+        out[f"resblocka_sd/{k}"] = v.numpy()
+    for k, prm in rb.named_parameters():
+        out[f"resblocka_grad/{k}"] = prm.grad.numpy()
+    psp = PSP_Pooling(8, [1, 2, 4, 8]).train()
+    x = torch.randn(2, 8, 16, 16, requires_grad=True)
+    y = psp(x)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    out["psp_block_x"], out["psp_block_y"], out["psp_block_gy"], out["psp_block_dx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    for k, v in psp.state_dict().items():
+        out[f"psp_block_sd/{k}"] = v.numpy()
+    for k, prm in psp.named_parameters():
+        out[f"psp_block_grad/{k}"] = prm.grad.numpy()
+    # the min_size check of ResBlockA (pssr/models/_blocks.py:62,66)
+    try:
+        ResBlockA(4, 4, [1, 7], 0)(torch.zeros(1, 4, 14, 14))
+        out["resblocka_small_raises"] = np.array(0)
+    except ValueError as e:
+        out["resblocka_small_raises"] = np.array(1)
+        out["resblocka_small_msg"] = np.array(str(e))
+    np.savez_compressed(OUT / "atrous.npz", **out)
+
+
 def gen_train_trace(pssr):
     """2-epoch train_paired trace on an in-memory dataset (MSELoss): pins step order,
     train/eval toggling, log cadence and the returned loss lists (pssr/train.py:19-166)."""
@@ -387,7 +471,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)   # deterministic summation order for the fixtures
     pssr = import_reference()
     only = sys.argv[1:]
-    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_metrics, gen_train_trace):
+    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_metrics, gen_atrous, gen_train_trace):
         if only and fn.__name__ not in only:
             continue
         fn(pssr)

@@ -64,6 +64,48 @@ def resblock_forward(x, sd, prefix, depth, train, new_stats, record=None, masks=
     return _rec(record, f"{prefix}.out", _relu(h + r, f"{prefix}.tail", masks, record))
 
 
+def resblock_a_forward(x, sd, prefix, dilations, depth, train, new_stats, record=None):
+    """ResBlockA.forward (pssr/models/_blocks.py:43-68): every dilation branch is [BatchNorm, ReLU, Conv3x3(dilation d, padding
+    "same")] x (depth + 1) laid out as Sequential indices 3k, 3k+1, 3k+2; the block is relu(sum of branches + conv1x1(x)).  The
+    in-place ReLU acts on the BatchNorm output, never on x.  Raises like upstream when the map is smaller than the largest kernel."""
+    min_size = max(dilations) * 2 + 1
+    if x.shape[-1] < min_size:
+        raise ValueError(f"Tensor size {x.shape} is smaller than than dilation kernel size {min_size}.")
+    n_layers = max(depth, 0) + 1
+    total = None
+    for di, d in enumerate(dilations):
+        h = x
+        for k in range(n_layers):
+            pre = f"{prefix}.dilations.{di}"
+            h = F.relu(_bn(h, sd, f"{pre}.{3 * k}", train, new_stats))
+            h = _rec(record, f"{pre}.y{k}", F.conv2d(h, sd[f"{pre}.{3 * k + 2}.weight"], sd[f"{pre}.{3 * k + 2}.bias"], padding=d, dilation=d))
+        total = h if total is None else total + h
+    r = F.conv2d(x, sd[f"{prefix}.respass.weight"], sd[f"{prefix}.respass.bias"])
+    return _rec(record, f"{prefix}.out", F.relu(total + r))
+
+
+def psp_forward(x, sd, prefix, sizes, train, new_stats, record=None):
+    """PSP_Pooling.forward (pssr/models/_blocks.py:82-92): torch.chunk along channels, per chunk max_pool2d(k) -> bilinear
+    interpolate back (align_corners=False) -> relu(BN(conv1x1)); concat; relu(BN(conv1x1))."""
+    size = x.shape[-2:]
+    chunks = torch.chunk(x, chunks=len(sizes), dim=1)
+    outs = []
+    for i, (ch, k) in enumerate(zip(chunks, sizes)):
+        ch = F.interpolate(F.max_pool2d(ch, kernel_size=k), size=size, mode="bilinear")
+        ch = F.conv2d(ch, sd[f"{prefix}.convs.{i}.0.weight"], sd[f"{prefix}.convs.{i}.0.bias"])
+        outs.append(F.relu(_bn(ch, sd, f"{prefix}.convs.{i}.1", train, new_stats)))
+    x = torch.cat(outs, dim=1)
+    x = F.conv2d(x, sd[f"{prefix}.conv_out.weight"], sd[f"{prefix}.conv_out.bias"])
+    return _rec(record, f"{prefix}.out", F.relu(_bn(x, sd, f"{prefix}.norm_out", train, new_stats)))
+
+
+def any_block_forward(x, sd, prefix, dilations, depth, train, new_stats, record=None, masks=None):
+    """get_resblock dispatch (pssr/models/_blocks.py:114-117)."""
+    if dilations:
+        return resblock_a_forward(x, sd, prefix, dilations, depth, train, new_stats, record)
+    return resblock_forward(x, sd, prefix, depth, train, new_stats, record, masks)
+
+
 def reconstruction_forward(x, sd, prefix, scale, record=None, masks=None):
     """pssr/models/_blocks.py:15-18."""
     x = F.conv2d(x, sd[f"{prefix}.pre.weight"], sd[f"{prefix}.pre.bias"], padding=1)
@@ -72,25 +114,32 @@ def reconstruction_forward(x, sd, prefix, scale, record=None, masks=None):
     return F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], padding=1)
 
 
-def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None, masks=None):
-    """ResUNet.forward (pssr/models/resunet.py:65-96), non-atrous, no PSP pooling.
+def resunet_forward(x, sd, n_levels, depth=3, scale=4, train=False, record=None, masks=None, dilations=None, pool_sizes=None,
+                    encoder_pool=False):
+    """ResUNet.forward (pssr/models/resunet.py:65-96) including the atrous (``dilations``: no input BatchNorm, ResBlockA blocks;
+    the decoder block j uses dilations[-j-1], resunet.py:58) and PSP-pooling (``pool_sizes`` / ``encoder_pool``) variants.
 
     ``x``: float32 [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats).
     """
     new_stats: dict[str, torch.Tensor] = {}
     x = x / 128 - 1
-    x = _bn(x, sd, "norm", train, new_stats)
+    if not dilations:
+        x = _bn(x, sd, "norm", train, new_stats)
     skips = [x]
     for i in range(n_levels):
-        x = resblock_forward(x, sd, f"encoder.{i}", depth, train, new_stats, record, masks)
+        x = any_block_forward(x, sd, f"encoder.{i}", dilations[i] if dilations else None, depth, train, new_stats, record, masks)
         if i + 1 < n_levels:
             skips.append(x)
             x = F.max_pool2d(x, kernel_size=2)
+    if pool_sizes and encoder_pool:
+        x = psp_forward(x, sd, "encoder_pool", pool_sizes, train, new_stats, record)
     for j in range(n_levels - 1):
         x = F.pixel_shuffle(x, 2)
         x = torch.cat([x, skips.pop()], dim=1)
         x = _rec(record, f"decoder.{j}.in", x)
-        x = resblock_forward(x, sd, f"decoder.{j}", depth, train, new_stats, record, masks)
+        x = any_block_forward(x, sd, f"decoder.{j}", dilations[-j - 1] if dilations else None, depth, train, new_stats, record, masks)
+    if pool_sizes:
+        x = psp_forward(x, sd, "reconstruction_pool", pool_sizes, train, new_stats, record)
     x = torch.cat([x, skips.pop()], dim=1)
     assert not skips
     x = reconstruction_forward(x, sd, "reconstruction", scale, record, masks)

@@ -112,19 +112,27 @@ def rdnet_forward(x, sd, cfg: RDConfig, prefix="encoder", record=None):
     return (*skips, x)
 
 
-def rdresunet_forward(x, sd, cfg: RDConfig, train=False, record=None, masks=None):
-    """RDResUNet.forward (pssr/models/rdresunet.py:104-130), non-atrous, no PSP pooling.
+def rdresunet_forward(x, sd, cfg: RDConfig, train=False, record=None, masks=None, dilations=None, pool_sizes=None, encoder_pool=False):
+    """RDResUNet.forward (pssr/models/rdresunet.py:104-130) including the atrous (``dilations``: no input BatchNorm, decoder block k
+    is a ResBlockA with dilations[k], rdresunet.py:92-95) and PSP-pooling variants (``encoder_pool`` acts on the deepest skip,
+    :112-113; ``reconstruction_pool`` in front of the final concatenation, :121-122).
     ``x``: float [N, C_in, H, W] in ~[0, 255].  Returns (y, new_running_stats)."""
+    from .model_ref import any_block_forward, psp_forward
     new_stats: dict[str, torch.Tensor] = {}
     x = x / 128 - 1
-    x = _bn(x, sd, "norm", train, new_stats)
+    if not dilations:
+        x = _bn(x, sd, "norm", train, new_stats)
     skips = [x]
     skips.extend(rdnet_forward(x, sd, cfg, "encoder", record))
+    if pool_sizes and encoder_pool:
+        skips[-1] = psp_forward(skips[-1], sd, "encoder_pool", pool_sizes, train, new_stats, record)
     for k in range(len(cfg.hidden)):
         x = torch.cat([x, skips.pop()], dim=1) if k else skips.pop()
         x = _rec(record, f"decoder.{k}.in", x)
-        x = resblock_forward(x, sd, f"decoder.{k}", cfg.depth, train, new_stats, record, masks)
+        x = any_block_forward(x, sd, f"decoder.{k}", dilations[k] if dilations else None, cfg.depth, train, new_stats, record, masks)
         x = F.pixel_shuffle(x, cfg.ratios[k + 1])
+    if pool_sizes:
+        x = psp_forward(x, sd, "reconstruction_pool", pool_sizes, train, new_stats, record)
     x = torch.cat([x, skips.pop()], dim=1)
     assert not skips
     x = reconstruction_forward(x, sd, "reconstruction", cfg.scale, record, masks)

@@ -12,6 +12,9 @@ def __getattr__(name):
     if name in ("RDResUNet",):
         from .models import RDResUNet
         return RDResUNet
+    if name in ("ResUNetA", "RDResUNetA"):
+        from . import models
+        return getattr(models, name)
     if name in ("SSIMLoss",):
         from .util import SSIMLoss
         return SSIMLoss

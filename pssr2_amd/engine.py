@@ -269,6 +269,7 @@ class Engine:
         self.cin, self.cout = m.channels
         self.hidden = list(m.hidden)
         self.L = len(self.hidden)
+        self.atrous = m.norm is None          # pssr/models/resunet.py:50: the atrous variant has no input BatchNorm
         self.r = m.reconstruction.scale
         self.blk = _log2(self.r)
         self.xc = ops.pad_to(9 * self.cin, 16)
@@ -304,6 +305,16 @@ class Engine:
         if c is None:
             c = self._convs[id(module)] = _Conv(module, specs, self._wepoch)
         return c
+
+    def _pw_any(self, module, name, code, **spec):
+        """Packed weight of any conv module under a packing spec (mode ...), cached per parameter version."""
+        c = self._convs.get(id(module))
+        if c is None:
+            c = self._convs[id(module)] = _Conv(module, {}, self._wepoch)
+        key = f"{name}:{spec.get('mode', 0)}"
+        if key not in c.specs:
+            c.specs[key] = dict(spec)
+        return c.get(key, code)
 
     def _check_supported(self, dtype_code, h, w, train):
         kch = 8 if dtype_code == L.F32 else 16
@@ -342,20 +353,41 @@ class Engine:
         # concat buffers: cat[l] = [shuffle(level l+1 output) | encoder l output]
         p.cat = [buf(*p.dims[l], hid[l + 1] // 4 + hid[l]) for l in range(Lv - 1)]
         p.pooled = [buf(*p.dims[l + 1], hid[l]) for l in range(Lv - 1)]
+        from . import atrous as A
+        from .models import ResBlockA
         for i in range(Lv):
             b = type("B", (), {})()
             b.level, b.c = i, hid[i]
-            b.y = [buf(*p.dims[i], hid[i]) for _ in range(nl)]
-            b.bn = [_BNState(hid[i], f32, f64) for _ in range(nl)]
+            b.a = None
+            if isinstance(m.encoder[i], ResBlockA):
+                b.a = A.make_ablock_state(m.encoder[i], n, *p.dims[i], self.cin if i == 0 else hid[i - 1], dt, device)
+                b.y, b.bn = [], []
+            else:
+                b.y = [buf(*p.dims[i], hid[i]) for _ in range(nl)]
+                b.bn = [_BNState(hid[i], f32, f64) for _ in range(nl)]
             b.out = None if i < Lv - 1 else buf(*p.dims[i], hid[i])       # encoder outputs live in cat[i]
             p.enc.append(b)
         for l in range(Lv - 1):
             b = type("B", (), {})()
             b.level, b.c = l, hid[l]
-            b.y = [buf(*p.dims[l], hid[l]) for _ in range(nl)]
-            b.bn = [_BNState(hid[l], f32, f64) for _ in range(nl)]
+            b.a = None
+            mod = m.decoder[Lv - 2 - l]
+            if isinstance(mod, ResBlockA):
+                b.a = A.make_ablock_state(mod, n, *p.dims[l], hid[l + 1] // 4 + hid[l], dt, device)
+                b.y, b.bn = [], []
+            else:
+                b.y = [buf(*p.dims[l], hid[l]) for _ in range(nl)]
+                b.bn = [_BNState(hid[l], f32, f64) for _ in range(nl)]
             b.out = buf(*p.dims[l], hid[l])
             p.dec.append(b)                                              # p.dec[l] is the block at level l
+        p.xin = buf(h, w, self.cin) if self.atrous else None              # plain "x / 128 - 1" for an atrous first block
+        p.epool = p.rpool = None
+        if getattr(m, "encoder_pool", None) is not None:
+            p.epool = A.make_psp_state(m.encoder_pool, n, *p.dims[Lv - 1], dt, device)
+            p.epool_out = buf(*p.dims[Lv - 1], hid[Lv - 1])
+        if getattr(m, "reconstruction_pool", None) is not None:
+            p.rpool = A.make_psp_state(m.reconstruction_pool, n, *p.dims[0], dt, device)
+            p.rpool_out = buf(*p.dims[0], hid[0])
         r2 = self.r * self.r
         p.pre = torch.zeros(n, h, w, r2 * hid[0], dtype=dt, device=device)
         p.f32 = f32.build(torch.float32, device)
@@ -392,6 +424,8 @@ class Engine:
         b.g_hr = torch.zeros(n, p.h * r, p.w * r, 16, dtype=dt, device=device)
         b.dpre = torch.zeros(n, p.h, p.w, r * r * hid[0], dtype=dt, device=device)
         b.sum64 = torch.zeros(ops.STAT_STRIPES * max(16, r * r * hid[0]), dtype=torch.float64, device=device)
+        b.drpool = buf(*p.dims[0], hid[0]) if getattr(p, "rpool", None) is not None else None
+        b.depool = buf(*p.dims[Lv - 1], hid[Lv - 1]) if getattr(p, "epool", None) is not None else None
         p.bwd = b
         return b
 
@@ -427,6 +461,10 @@ class Engine:
                 st.eval_key = key
 
     def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
+        if getattr(blk, "a", None) is not None:          # ResBlockA (pssr2_amd/atrous.py); a first block reads the plain input
+            from . import atrous as A
+            A.ablock_forward(self, blk.a, module, p.xin if first else src, 0, p.n, p.code, dst, dst_coff, train)
+            return
         n = p.n
         hh, ww = p.dims[blk.level]
         count = float(n * hh * ww)
@@ -475,8 +513,13 @@ class Engine:
         if train:
             p.f64.buf.zero_()
             self._count_batches()
-            ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
-        self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
+        if self.atrous:
+            p.bn_in.scale.fill_(1.0), p.bn_in.shift.zero_()          # no input BatchNorm: xcol is the im2col of x / 128 - 1 itself
+            ops.input_plain(x, p.xin, code)
+        else:
+            if train:
+                ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
+            self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
         ops.input_im2col(x, p.xcol, p.bn_in.scale, p.bn_in.shift, code)
         # encoder
         for i in range(Lv):
@@ -489,13 +532,22 @@ class Engine:
             self._block_forward(p, blk, m.encoder[i], src, cin, i == 0, dst, off, train)
             if i < Lv - 1:
                 ops.maxpool2(dst, p.pooled[i], n, *p.dims[i], hid[i], code, in_coff=off)
+        deep = p.enc[Lv - 1].out
+        if p.epool is not None:         # pssr/models/resunet.py:78-79
+            from . import atrous as A
+            A.psp_forward(self, p.epool, m.encoder_pool, deep, 0, n, code, p.epool_out, 0, train)
+            deep = p.epool_out
         # decoder
         for l in range(Lv - 2, -1, -1):
-            prev = p.enc[Lv - 1].out if l == Lv - 2 else p.dec[l + 1].out
+            prev = deep if l == Lv - 2 else p.dec[l + 1].out
             ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
             blk = p.dec[l]
             self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train)
-        feat = p.dec[0].out if Lv > 1 else p.enc[0].out
+        feat = p.dec[0].out if Lv > 1 else deep
+        if p.rpool is not None:         # pssr/models/resunet.py:87-88
+            from . import atrous as A
+            A.psp_forward(self, p.rpool, m.reconstruction_pool, feat, 0, n, code, p.rpool_out, 0, train)
+            feat = p.rpool_out
         out = self._head_forward(p, feat, x)
         self.saved = (p, x) if train else None
         return out
@@ -609,6 +661,10 @@ class Engine:
 
     def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
         """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc."""
+        if getattr(blk, "a", None) is not None:
+            from . import atrous as A
+            A.ablock_backward(self, blk.a, module, grads, p.xin if first else src, 0, p.n, p.code, out_buf, out_coff, dout, 0, dsrc, not first)
+            return
         n, code = p.n, p.code
         lvl = blk.level
         hh, ww = p.dims[lvl]
@@ -672,8 +728,15 @@ class Engine:
         h0 = hid[0]
         grads = {}
         self._begin_backward(dev)
-        feat = p.dec[0].out if Lv > 1 else p.enc[0].out
-        self._head_backward(p, bw, grads, dout, feat, bw.dout[0])
+        from . import atrous as A
+        deep = p.epool_out if p.epool is not None else p.enc[Lv - 1].out
+        feat0 = p.dec[0].out if Lv > 1 else deep
+        feat = p.rpool_out if p.rpool is not None else feat0
+        if p.rpool is not None:
+            self._head_backward(p, bw, grads, dout, feat, bw.drpool)
+            A.psp_backward(self, p.rpool, m.reconstruction_pool, grads, feat0, 0, n, code, p.rpool_out, 0, bw.drpool, 0, bw.dout[0], 0)
+        else:
+            self._head_backward(p, bw, grads, dout, feat, bw.dout[0])
         # ---- decoder, bottom-up in the data-flow sense (level 0 first)
         for l in range(0, Lv - 1):
             blk = p.dec[l]
@@ -681,6 +744,9 @@ class Engine:
                                  blk.out, 0, bw.dout[l], bw.dcat[l], hid[l + 1] // 4 + hid[l])
             # split dcat: [0, h_{l+1}/4) -> un-shuffle to the producer at level l+1
             ops.pixel_shuffle(bw.dout[l + 1], bw.dcat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code, inverse=True)
+        if p.epool is not None:         # bw.dout[Lv-1] is the gradient of the pooled map: back through the PSP block
+            A.psp_backward(self, p.epool, m.encoder_pool, grads, p.enc[Lv - 1].out, 0, n, code, p.epool_out, 0, bw.dout[Lv - 1], 0, bw.depool, 0)
+            bw.dout[Lv - 1], bw.depool = bw.depool, bw.dout[Lv - 1]
         # ---- encoder, deepest first
         for i in range(Lv - 1, -1, -1):
             blk = p.enc[i]
@@ -700,6 +766,8 @@ class Engine:
             if split_cb is not None and i == Lv - 1 and Lv > 1:
                 self._side_join()
                 split_cb()
+        if self.atrous:                 # no input BatchNorm, and the network input needs no gradient
+            return self._finish_backward(grads)
         # ---- input BatchNorm parameters
         st = p.bn_in
         st.bstats.zero_()

@@ -50,6 +50,48 @@ class ResBlock(nn.Module):
         self.depth = depth
 
 
+class ResBlockA(nn.Module):
+    """Pre-activation atrous block: relu(sum_d [BN, ReLU, conv3x3(dilation d, padding "same")]*(depth+1) + conv1x1)
+    (pssr/models/_blocks.py:43-68); ``min_size`` check as upstream (:62,:66)."""
+
+    def __init__(self, in_channels: int, out_channels: int, dilations, depth: int):
+        super().__init__()
+        self.dilations = nn.ModuleList()
+        for dilation in dilations:
+            conv = nn.Sequential()
+            n_layers = max(depth, 0) + 1
+            for k in range(n_layers):
+                conv.append(nn.BatchNorm2d(in_channels if k == 0 else out_channels))
+                conv.append(nn.ReLU(inplace=True))
+                conv.append(nn.Conv2d(in_channels if k == 0 else out_channels, out_channels, kernel_size=3, padding="same", dilation=dilation))
+            self.dilations.append(conv)
+        self.respass = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.dilation_values = [int(d) for d in dilations]
+        self.min_size = max(dilations) * 2 + 1
+        self.depth = depth
+
+
+class PSP_Pooling(nn.Module):
+    """Pyramid pooling: channel chunks -> max_pool2d(k) -> bilinear resize back -> conv1x1 + BN + ReLU, concatenated, then
+    conv1x1 + BN + ReLU (pssr/models/_blocks.py:70-92)."""
+
+    def __init__(self, channels, sizes):
+        super().__init__()
+        small = channels // len(sizes)
+        self.convs = nn.ModuleList([nn.Sequential(nn.Conv2d(small, small, kernel_size=1), nn.BatchNorm2d(small)) for _ in sizes])
+        self.conv_out = nn.Conv2d(channels, channels, kernel_size=1)
+        self.norm_out = nn.BatchNorm2d(channels)
+        self.sizes = list(sizes)
+        self.channels = channels
+
+
+def get_resblock(in_channels: int, out_channels: int, dilations, depth: int):
+    """pssr/models/_blocks.py:114-117."""
+    if dilations:
+        return ResBlockA(in_channels, out_channels, dilations, depth)
+    return ResBlock(in_channels, out_channels, depth)
+
+
 class _EngineFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are engine kernel sequences."""
 
@@ -76,8 +118,8 @@ class ResUNet(nn.Module):
     def __init__(self, channels=1, hidden=[64, 128, 256, 512, 1024], scale: int = 4, depth: int = 3,
                  dilations=None, pool_sizes=None, encoder_pool: bool = False):
         r"""Residual U-Net with a ``scale``-times upscaling head; same arguments as the reference
-        (pssr/models/resunet.py:8-17).  ``dilations`` / ``pool_sizes`` (the atrous / PSP variants,
-        SURVEY.md §8f-4) are validated like the reference but not implemented on the MI355X path.
+        (pssr/models/resunet.py:8-17), including ``dilations`` (atrous blocks, no input BatchNorm) and ``pool_sizes`` /
+        ``encoder_pool`` (PSP pooling): SURVEY.md §8f-4.
 
         Extra attribute: ``compute_dtype``: torch.float32 (exact-f32 MFMA, default), torch.bfloat16 or torch.float16
         (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16).
@@ -95,17 +137,18 @@ class ResUNet(nn.Module):
                 raise ValueError(f"hidden[-1] must be divisible by len(pool_sizes) if encoder_pool is True. Given values are {hidden[-1]} and {len(pool_sizes)} respectively.")
         elif encoder_pool:
             raise ValueError("encoder_pool cannot be True if pool_sizes are not provided.")
-        if dilations or pool_sizes:
-            raise NotImplementedError("atrous / PSP-pooling ResUNet variants are not implemented on the MI355X path yet")
 
-        self.norm = nn.BatchNorm2d(channels[0])
+        self.norm = nn.BatchNorm2d(channels[0]) if not dilations else None
         self.encoder, self.decoder = nn.ModuleList(), nn.ModuleList()
         layers = [channels[0], *hidden]
         n_layers = len(layers) - 1
         for i in range(n_layers):     # encoder i then decoder i: the reference's creation (= RNG) order
-            self.encoder.append(ResBlock(layers[i], layers[i + 1], depth))
+            self.encoder.append(get_resblock(layers[i], layers[i + 1], dilations[i] if dilations else None, depth))
             if i + 1 < n_layers:
-                self.decoder.append(ResBlock(layers[-i - 1] - int(layers[-i - 2] / 2), layers[-i - 2], depth))
+                self.decoder.append(get_resblock(layers[-i - 1] - int(layers[-i - 2] / 2), layers[-i - 2],
+                                                 dilations[-i - 1] if dilations else None, depth))
+        self.encoder_pool = PSP_Pooling(hidden[-1], pool_sizes) if pool_sizes and encoder_pool else None
+        self.reconstruction_pool = PSP_Pooling(hidden[0], pool_sizes) if pool_sizes else None
         self.reconstruction = Reconstruction(channels[0], channels[1], hidden[0], scale)
 
         self.channels, self.hidden, self.depth = channels, hidden, depth
@@ -117,8 +160,16 @@ class ResUNet(nn.Module):
         return _EngineFunction.apply(self._engine, x, *params)
 
     def extra_repr(self):
-        return (f"ResUNet with {self.reconstruction.scale}x upscaling\n{len(self.encoder)} residual decoder blocks with "
-                f"{self.encoder[0].depth} hidden layers each\nPSP pooling disabled")
+        return (f"{'Atrous ' if self.norm is None else ''}ResUNet with {self.reconstruction.scale}x upscaling\n{len(self.encoder)} residual decoder blocks with "
+                f"{self.encoder[0].depth} hidden layers each\nPSP pooling {'enabled' if self.reconstruction_pool else 'disabled'}")
+
+
+class ResUNetA:
+    """``ResUNet`` with the reference's atrous defaults (pssr/models/resunet.py:101-139)."""
+
+    def __new__(cls, channels=1, hidden=[64, 128, 256, 512, 1024], scale: int = 4, depth: int = 3,
+                dilations=[[1, 3, 15, 31], [1, 3, 15], [1, 3], [1], [1]], pool_sizes=[1, 2, 4, 8], encoder_pool: bool = False):
+        return ResUNet(channels, hidden, scale, depth, dilations, pool_sizes, encoder_pool)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -246,7 +297,7 @@ class RDResUNet(nn.Module):
                  n_blocks=[3, 3, 3, 3, 3, 3, 3], patch_size: int = 2, bottleneck: int = 4, compression: float = 0.5, drop_rate: float = 0):
         r"""RDNet (Revitalized DenseNet) encoder + ResUNet decoder + upscaling head; same arguments, module tree and
         ``state_dict`` as the reference (pssr/models/rdresunet.py:9-102).  ``dilations`` / ``pool_sizes`` are validated like
-        the reference but not implemented on the MI355X path; ``drop_rate`` is a no-op upstream too (_rdnet.py:161,168-175).
+        the reference and build the atrous / PSP variants; ``drop_rate`` is a no-op upstream too (_rdnet.py:161,168-175).
 
         Extra attribute: ``compute_dtype`` (torch.float32 — exact-f32 MFMA — torch.bfloat16 or torch.float16).
         """
@@ -263,9 +314,7 @@ class RDResUNet(nn.Module):
                 raise ValueError(f"hidden[-1] must be divisible by len(pool_sizes) if encoder_pool is True. Given values are {hidden[-1]} and {len(pool_sizes)} respectively.")
         elif encoder_pool:
             raise ValueError("encoder_pool cannot be True if pool_sizes are not provided.")
-        if dilations or pool_sizes:
-            raise NotImplementedError("atrous / PSP-pooling RDResUNet variants are not implemented on the MI355X path yet")
-        self.norm = nn.BatchNorm2d(channels[0])
+        self.norm = nn.BatchNorm2d(channels[0]) if not dilations else None
         if sum(ds_blocks) != len(hidden) - 1:
             raise ValueError(f"Number of downsampling blocks must be one less than ResUNet hidden layers. Given {sum(ds_blocks)} downsampling blocks but {len(hidden)} hidden layers.")
         # positional order as upstream (rdresunet.py:84): ese_blocks lands in block_type, drop_rate in drop_path_rate
@@ -278,7 +327,9 @@ class RDResUNet(nn.Module):
         layers = [0, *hidden]
         self.decoder = nn.ModuleList()
         for k in range(len(layers) - 1):
-            self.decoder.append(ResBlock(layers[k] // self.ratios[k] ** 2 + skips[k], layers[k + 1], depth))
+            self.decoder.append(get_resblock(layers[k] // self.ratios[k] ** 2 + skips[k], layers[k + 1], dilations[k] if dilations else None, depth))
+        self.encoder_pool = PSP_Pooling(skips[0], pool_sizes) if pool_sizes and encoder_pool else None
+        self.reconstruction_pool = PSP_Pooling(hidden[-1] // self.ratios[-1] ** 2, pool_sizes) if pool_sizes else None
         self.reconstruction = Reconstruction(channels[0], channels[1], hidden[-1] // self.ratios[-1] ** 2, scale)
         self.skips = skips
         self.channels, self.hidden, self.depth = channels, hidden, depth
@@ -291,5 +342,16 @@ class RDResUNet(nn.Module):
         return _EngineFunction.apply(self._engine, x, *params)
 
     def extra_repr(self):
-        return (f"RDResUNet with {self.reconstruction.scale}x upscaling\n{len(self.decoder)} residual blocks with "
-                f"{self.decoder[0].depth} hidden layers each\nSkip connection sizes: {self.skips}\nPSP pooling disabled")
+        return (f"{'Atrous ' if self.norm is None else ''}RDResUNet with {self.reconstruction.scale}x upscaling\n{len(self.decoder)} residual blocks with "
+                f"{self.decoder[0].depth} hidden layers each\nSkip connection sizes: {self.skips}\nPSP pooling {'enabled' if self.reconstruction_pool else 'disabled'}")
+
+
+class RDResUNetA:
+    """``RDResUNet`` with the reference's atrous defaults (pssr/models/rdresunet.py:135-211)."""
+
+    def __new__(cls, channels=1, hidden=[1024, 1024, 512, 256], scale: int = 4, depth: int = 3, dilations=[[1], [1], [1, 3], [1, 3, 15]],
+                pool_sizes=[1, 2, 4, 8], encoder_pool: bool = False, rdnet_init: int = 128, growth_rates=[64, 104, 128, 128, 128, 128, 224],
+                ds_blocks=[False, True, True, False, False, False, True], ese_blocks=[False, False, True, True, True, True, True],
+                n_blocks=[3, 3, 3, 3, 3, 3, 3], patch_size: int = 2, bottleneck: int = 4, compression: float = 0.5, drop_rate: float = 0):
+        return RDResUNet(channels, hidden, scale, depth, dilations, pool_sizes, encoder_pool, rdnet_init, growth_rates, ds_blocks, ese_blocks,
+                         n_blocks, patch_size, bottleneck, compression, drop_rate)

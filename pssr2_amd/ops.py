@@ -523,3 +523,66 @@ def copy_f32_batch(pairs):
                 raise ValueError("copy_f32_batch needs contiguous float32 tensors of equal size")
             items.dst[i], items.src[i], items.n[i] = dst.data_ptr(), src.data_ptr(), dst.numel()
         L.check(L.lib().pssr_copy_f32_batch(C.byref(items), len(chunk), L.stream_ptr()), "pssr_copy_f32_batch")
+
+
+# ------------------------------------------------------------------ atrous / PSP variants (csrc/atrous.hip)
+def input_plain(x, out, dtype, pre_scale=1 / 128, pre_shift=-1.0):
+    n, c, h, w = x.shape
+    L.check(L.lib().pssr_input_plain(L.ptr(x), L.ptr(out), n, c, h, w, out.shape[-1], C.c_float(pre_scale), C.c_float(pre_shift), dtype,
+                                     L.stream_ptr()), "pssr_input_plain")
+
+
+def im2col_dil(x, c, col, cp, n, h, w, dil, dtype, in_coff=0, scale=None, shift=None):
+    L.check(L.lib().pssr_im2col_dil(L.ptr(x), x.shape[-1], in_coff, c, L.ptr(scale), L.ptr(shift), L.ptr(col), cp, n, h, w, dil, dtype,
+                                    L.stream_ptr()), "pssr_im2col_dil")
+
+
+def col2im_dil(dcol, cp, out, c, n, h, w, dil, dtype, out_coff=0, y=None, y_coff=0, scale=None, shift=None, mean=None, invstd=None, stats=None):
+    L.check(L.lib().pssr_col2im_dil(L.ptr(dcol), cp, L.ptr(out), out.shape[-1], out_coff, c, n, h, w, dil, L.ptr(y),
+                                    y.shape[-1] if y is not None else 0, y_coff, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
+                                    L.ptr(stats), dtype, L.stream_ptr()), "pssr_col2im_dil")
+
+
+def channel_stats_nhwc(x, c, npix, stats, dtype, coff=0):
+    L.check(L.lib().pssr_channel_stats_nhwc(L.ptr(x), x.shape[-1], coff, c, C.c_int64(npix), L.ptr(stats), dtype, L.stream_ptr()),
+            "pssr_channel_stats_nhwc")
+
+
+def sum_relu(ins, out, npix, c, dtype, relu=True, out_coff=0):
+    """ins: list of (tensor, channel offset)."""
+    k = len(ins)
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t, _ in ins])
+    css = (C.c_int * k)(*[t.shape[-1] for t, _ in ins])
+    cos = (C.c_int * k)(*[o for _, o in ins])
+    L.check(L.lib().pssr_sum_relu(ptrs, css, cos, k, L.ptr(out), out.shape[-1], out_coff, C.c_int64(npix), c, int(relu), dtype, L.stream_ptr()),
+            "pssr_sum_relu")
+
+
+def relu_mask(dout, out, dz, npix, c, dtype, do_coff=0, o_coff=0, dz_coff=0):
+    L.check(L.lib().pssr_relu_mask(L.ptr(dout), dout.shape[-1], do_coff, L.ptr(out), out.shape[-1], o_coff, L.ptr(dz), dz.shape[-1], dz_coff,
+                                   C.c_int64(npix), c, dtype, L.stream_ptr()), "pssr_relu_mask")
+
+
+def affine_relu(x, scale, shift, out, npix, c, dtype, coff=0, out_coff=0):
+    L.check(L.lib().pssr_affine_relu(L.ptr(x), x.shape[-1], coff, L.ptr(scale), L.ptr(shift), L.ptr(out), out.shape[-1], out_coff, C.c_int64(npix), c,
+                                     dtype, L.stream_ptr()), "pssr_affine_relu")
+
+
+def maxpool_k(x, out, n, h, w, c, k, dtype, in_coff=0, out_coff=0):
+    L.check(L.lib().pssr_maxpool_k(L.ptr(x), x.shape[-1], in_coff, L.ptr(out), out.shape[-1], out_coff, n, h, w, c, k, dtype, L.stream_ptr()),
+            "pssr_maxpool_k")
+
+
+def maxpool_k_bwd(act, dpool, dx, n, h, w, c, k, dtype, act_coff=0, dp_coff=0, dx_coff=0):
+    L.check(L.lib().pssr_maxpool_k_bwd(L.ptr(act), act.shape[-1], act_coff, L.ptr(dpool), dpool.shape[-1], dp_coff, L.ptr(dx), dx.shape[-1], dx_coff,
+                                       n, h, w, c, k, dtype, L.stream_ptr()), "pssr_maxpool_k_bwd")
+
+
+def bilinear_up(x, out, n, hs, ws, h, w, c, dtype, in_coff=0, out_coff=0):
+    L.check(L.lib().pssr_bilinear_up(L.ptr(x), x.shape[-1], in_coff, L.ptr(out), out.shape[-1], out_coff, n, hs, ws, h, w, c, dtype, L.stream_ptr()),
+            "pssr_bilinear_up")
+
+
+def bilinear_up_bwd(dout, din, n, hs, ws, h, w, c, dtype, do_coff=0, di_coff=0):
+    L.check(L.lib().pssr_bilinear_up_bwd(L.ptr(dout), dout.shape[-1], do_coff, L.ptr(din), din.shape[-1], di_coff, n, hs, ws, h, w, c, dtype,
+                                         L.stream_ptr()), "pssr_bilinear_up_bwd")

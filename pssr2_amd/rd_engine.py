@@ -73,6 +73,7 @@ class RDEngine(Engine):
         enc = m.encoder
         self.cin, self.cout = m.channels
         self.hidden = list(m.hidden)
+        self.atrous = m.norm is None          # pssr/models/rdresunet.py:80
         self.r = m.reconstruction.scale
         self.blk = _log2(self.r)
         self.ps = enc.patch_size
@@ -148,13 +149,27 @@ class RDEngine(Engine):
         p.cat = [buf(*p.dims[k], p.shuf_c[k] + m.skips[k]) for k in range(nd)]
         nl = max(m.depth, 0) + 1
         p.dec = []
+        from . import atrous as A
+        from .models import ResBlockA
         for k in range(nd):
-            b = _obj(level=k, c=hid[k])
-            b.y = [buf(*p.dims[k], hid[k]) for _ in range(nl)]
-            b.bn = [_BNState(hid[k], f32, f64) for _ in range(nl)]
+            b = _obj(level=k, c=hid[k], a=None)
+            if isinstance(m.decoder[k], ResBlockA):
+                b.a = A.make_ablock_state(m.decoder[k], n, *p.dims[k], p.shuf_c[k] + m.skips[k], dt, device)
+                b.y, b.bn = [], []
+            else:
+                b.y = [buf(*p.dims[k], hid[k]) for _ in range(nl)]
+                b.bn = [_BNState(hid[k], f32, f64) for _ in range(nl)]
             b.out = buf(*p.dims[k], hid[k])
             p.dec.append(b)
         p.feat = buf(h, w, self.h0)
+        p.xin = None
+        p.epool = p.rpool = None
+        if getattr(m, "encoder_pool", None) is not None:         # acts on the deepest skip (rdresunet.py:112-113)
+            p.epool = A.make_psp_state(m.encoder_pool, n, *p.dims[0], dt, device)
+            p.epool_out = buf(*p.dims[0], m.skips[0])
+        if getattr(m, "reconstruction_pool", None) is not None:
+            p.rpool = A.make_psp_state(m.reconstruction_pool, n, h, w, dt, device)
+            p.rpool_out = buf(h, w, self.h0)
         r2 = self.r * self.r
         p.pre = torch.zeros(n, h, w, r2 * self.h0, dtype=dt, device=device)
         # encoder stages
@@ -233,6 +248,8 @@ class RDEngine(Engine):
         b.dout = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dcat = [buf(*p.dims[k], p.shuf_c[k] + m.skips[k]) for k in range(nd)]
         b.dfeat = buf(p.h, p.w, self.h0)
+        b.drpool = buf(p.h, p.w, self.h0) if p.rpool is not None else None
+        b.depool = buf(*p.dims[0], m.skips[0]) if p.epool is not None else None
         b.dxcol_b = buf(p.h, p.w, self.xc)
         b.dxpatch = buf(*p.enc_dims[0], self.pc)
         r = self.r
@@ -328,8 +345,12 @@ class RDEngine(Engine):
         if train:
             p.f64.buf.zero_()
             self._count_batches()
-            ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
-        self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
+        if self.atrous:
+            p.bn_in.scale.fill_(1.0), p.bn_in.shift.zero_()          # no input BatchNorm
+        else:
+            if train:
+                ops.channel_stats_nchw(x, p.bn_in.stats, 1 / 128, -1.0)
+            self._bn_forward(p, p.bn_in, m.norm, float(n * h * w), train)
         ops.input_im2col(x, p.xcol, p.bn_in.scale, p.bn_in.shift, code)
         ops.input_patchify(x, p.xpatch, p.bn_in.scale, p.bn_in.shift, self.ps, code)
         p.small.buf.zero_()
@@ -367,15 +388,24 @@ class RDEngine(Engine):
                     gate = bk.gate
                 ops.scale_nc(bk.t, gate, bk.mod.gamma, None, st.F, n, st.h * st.w, st.g, code, out_coff=st.coff + bk.off)
         # ---- decoder
+        from . import atrous as A
         for k in range(nd):
             blk = p.dec[k]
-            self._block_forward(p, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, train)
+            src = p.cat[k]
+            if k == 0 and p.epool is not None:
+                A.psp_forward(self, p.epool, m.encoder_pool, p.cat[0], 0, n, code, p.epool_out, 0, train)
+                src = p.epool_out
+            self._block_forward(p, blk, m.decoder[k], src, src.shape[-1], False, blk.out, 0, train)
             r = m.ratios[k + 1]
             if k + 1 < nd:
                 ops.pixel_shuffle(blk.out, p.cat[k + 1], n, *p.dims[k], hid[k] // (r * r), r, code)
             else:
                 ops.pixel_shuffle(blk.out, p.feat, n, *p.dims[k], self.h0, r, code)
-        out = self._head_forward(p, p.feat, x)
+        feat = p.feat
+        if p.rpool is not None:
+            A.psp_forward(self, p.rpool, m.reconstruction_pool, p.feat, 0, n, code, p.rpool_out, 0, train)
+            feat = p.rpool_out
+        out = self._head_forward(p, feat, x)
         self.saved = (p, x) if train else None
         return out
 
@@ -460,7 +490,12 @@ class RDEngine(Engine):
         self._begin_backward(dev)
         for arena in (self._z64, self._z32):
             arena.begin(dev)
-        self._head_backward(p, bw, grads, dout, p.feat, bw.dfeat)
+        from . import atrous as A
+        if p.rpool is not None:
+            self._head_backward(p, bw, grads, dout, p.rpool_out, bw.drpool)
+            A.psp_backward(self, p.rpool, m.reconstruction_pool, grads, p.feat, 0, n, code, p.rpool_out, 0, bw.drpool, 0, bw.dfeat, 0)
+        else:
+            self._head_backward(p, bw, grads, dout, p.feat, bw.dfeat)
         # ---- decoder, last block first
         for k in range(nd - 1, -1, -1):
             blk = p.dec[k]
@@ -469,8 +504,13 @@ class RDEngine(Engine):
                 ops.pixel_shuffle(bw.dout[k], bw.dcat[k + 1], n, *p.dims[k], hid[k] // (rr * rr), rr, code, inverse=True)
             else:
                 ops.pixel_shuffle(bw.dout[k], bw.dfeat, n, *p.dims[k], h0, rr, code, inverse=True)
-            self._block_backward(p, bw, grads, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, bw.dout[k], bw.dcat[k],
-                                 p.shuf_c[k] + m.skips[k])
+            if k == 0 and p.epool is not None:
+                self._block_backward(p, bw, grads, blk, m.decoder[k], p.epool_out, p.epool_out.shape[-1], False, blk.out, 0, bw.dout[k], bw.depool,
+                                     m.skips[0])
+                A.psp_backward(self, p.epool, m.encoder_pool, grads, p.cat[0], 0, n, code, p.epool_out, 0, bw.depool, 0, bw.dcat[0], 0)
+            else:
+                self._block_backward(p, bw, grads, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, bw.dout[k], bw.dcat[k],
+                                     p.shuf_c[k] + m.skips[k])
         if split_cb is not None:       # reconstruction + decoder gradients (the tail of the flat buffer) are final
             self._side_join()
             split_cb()
@@ -511,6 +551,8 @@ class RDEngine(Engine):
         self._wgrad1x1(p, grads, stem_conv, bw.dstem, c0, 0, p.xpatch, self.pc, st0.h, st0.w, mode=2)
         ops.conv2d(bw.dstem, ops.pad_to(c0, 16), self._pw(stem_conv, "dgrad", code, mode=3), bw.dxpatch, self.pc, n=n, h=st0.h, w=st0.w)
         self._ready(grads, list(enc.stem.parameters()))
+        if self.atrous:                 # no input BatchNorm
+            return self._finish_backward(grads)
         # ---- input BatchNorm parameters (gradient sources: head im2col + stem patches)
         stn = p.bn_in
         stn.bstats.zero_()
