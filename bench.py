@@ -221,6 +221,8 @@ def main():
     args = ap.parse_args()
     if args.no_graph:
         os.environ["PSSR_GRAPH"] = "0"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ["PSSR_COMM_STATS"] = "1"
     if args.warmup < 3 and not args.no_graph:
         args.warmup = 3                     # two eager steps + the capture come first (pssr2_amd/fastpath.py)
 
@@ -398,6 +400,30 @@ def main():
                                "measured_in": "instrumented eager passes after the timed region: the same kernels one at a time on the launch stream, HIP events "
                                               "(the timed region replays them from a hipGraph with the weight-gradient kernels overlapping on a second stream)"}
 
+    # ---- N > 1: what the gradient exchange costs and how much of it the backward pass hides
+    if world > 1 and args.mode == "train":
+        from pssr2_amd import fastpath
+        flat = model._engine._flat_grad
+        probe = torch.zeros_like(flat)
+        ts = []
+        for i in range(4):
+            barrier()
+            t0 = time.perf_counter()
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        comm_ms = 1e3 * min(ts[1:])
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, (rank, local, os.uname().nodename))
+        stp = fastpath.LAST_TRAIN_STEPPER
+        exposed = stp.exposed_comm_ms(last=args.steps) if stp is not None else None
+        if rank == 0:
+            res["comm"] = {"allreduce_bytes_per_step": int(flat.numel() * 4), "comm_ms": round(comm_ms, 3),
+                           "comm_ms_is": "one all-reduce of the whole flat gradient buffer, nothing else running (min of 3)",
+                           "exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+                           "overlap_frac": None if exposed is None else round(max(0.0, 1.0 - exposed / comm_ms), 3),
+                           "split_graph": bool(stp is not None and stp.graph2 is not None), "ranks_seen": sorted(ranks),
+                           "bus_GBps": round(2 * (world - 1) / world * flat.numel() * 4 / (comm_ms * 1e-3) / 1e9, 1)}
     # ---- extra legs (rank 0 of a 1-GPU run): inference, sheet, exact-f32 training, CPU oracle
     if rank == 0 and world == 1 and args.mode == "train" and not args.no_extras and args.model == "resunet" and args.channels == 1:
         try:

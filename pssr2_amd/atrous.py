@@ -32,9 +32,11 @@ def _bn_alloc(c, dev):
     return st
 
 
-def _bn_fwd(eng, st, bn, stats, count, train):
+def _bn_fwd(eng, st, bn, stats, count, train, synced=False):
     if train:
         st.eval_key = None
+        if not synced:
+            count = eng.bn_stats_count(stats, count)          # sync_bn: statistics over all ranks
         ops.bn_finalize(stats, count, bn.weight, bn.bias, BN_EPS, BN_MOMENTUM, bn.running_mean, bn.running_var, st.scale[:st.c], st.shift[:st.c],
                         st.mean[:st.c], st.invstd[:st.c])
     else:
@@ -95,16 +97,21 @@ def ablock_forward(eng, st, module, src, src_coff, n, code, dst, dst_coff, train
         raise ValueError(f"Tensor size {(n, cin, hh, ww)} is smaller than than dilation kernel size {module.min_size}.")
     npix = n * hh * ww
     count = float(npix)
+    count_in = count
     if train:
         st.stats_in.zero_()
         ops.channel_stats_nhwc(src, cin, npix, st.stats_in, code, coff=src_coff)
+        count_in = eng.bn_stats_count(st.stats_in, count)     # shared by the first BatchNorm of every branch: reduced over ranks once
     for br, dil, seq in zip(st.br, st.dils, module.dilations):
         for k in range(st.nl):
             bn, conv = seq[3 * k], seq[3 * k + 2]
             bs = br.bn[k]
             if train and k + 1 < st.nl:
                 br.bn[k + 1].stats.zero_()
-            _bn_fwd(eng, bs, bn, st.stats_in if k == 0 else bs.stats, count, train)
+            if k == 0:
+                _bn_fwd(eng, bs, bn, st.stats_in, count_in, train, synced=True)
+            else:
+                _bn_fwd(eng, bs, bn, bs.stats, count, train)
             inp, ioff, ci = (src, src_coff, cin) if k == 0 else (br.y[k - 1], 0, c)
             cp = ops.pad_to(ci, 16)
             col = st.col.view(-1)[:npix * 9 * cp].view(n, hh, ww, 9 * cp)
@@ -163,7 +170,7 @@ def ablock_backward(eng, st, module, grads, src, src_coff, n, code, out_buf, out
             ops.col2im_dil(dcol, cp, b.g, ci, n, hh, ww, dil, code, y=inp, y_coff=ioff, scale=bs.scale, shift=bs.shift, mean=bs.mean,
                            invstd=bs.invstd, stats=bs.bstats)
             dgam, dbet = eng._gbuf(bn.weight), eng._gbuf(bn.bias)
-            ops.bn_bwd_coefs(bs.bstats, count, bn.weight, bs.mean[:ci], bs.invstd[:ci], bs.ca[:ci], bs.cb[:ci], bs.cc[:ci], dgam, dbet)
+            eng.bn_coefs(bs.bstats, count, bn.weight, bs.mean[:ci], bs.invstd[:ci], bs.ca[:ci], bs.cb[:ci], bs.cc[:ci], dgam, dbet)
             grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
             if k > 0:
                 nxt = b.dy[k & 1]
@@ -253,7 +260,7 @@ def psp_backward(eng, st, module, grads, src, src_coff, n, code, out_buf, out_co
     so.bstats.zero_()
     ops.relu_bwd_stats(dout, out_buf, st.v, so.mean, so.invstd, b.dz, so.bstats, npix, C, code, out_coff=out_coff)
     dgam, dbet = eng._gbuf(bo.weight), eng._gbuf(bo.bias)
-    ops.bn_bwd_coefs(so.bstats, count, bo.weight, so.mean, so.invstd, so.ca, so.cb, so.cc, dgam, dbet)
+    eng.bn_coefs(so.bstats, count, bo.weight, so.mean, so.invstd, so.ca, so.cb, so.cc, dgam, dbet)
     grads[id(bo.weight)], grads[id(bo.bias)] = dgam, dbet
     ops.bn_bwd_apply(b.dz, st.v, so.ca, so.cb, so.cc, b.dv, npix, C, code)
     # ---- conv_out over relu(BN_i(u_i)) (its bias precedes a batch-statistics BatchNorm: exactly zero gradient)
@@ -264,7 +271,7 @@ def psp_backward(eng, st, module, grads, src, src_coff, n, code, out_buf, out_co
                aux=st.u, aux_scale=sa.scale, aux_shift=sa.shift, aux_mean=sa.mean, aux_invstd=sa.invstd, stats=sa.bstats)
     for i in range(len(st.sizes)):
         b.gamma_all[i * small:(i + 1) * small].copy_(module.convs[i][1].weight.detach())
-    ops.bn_bwd_coefs(sa.bstats, count, b.gamma_all[:C], sa.mean[:C], sa.invstd[:C], sa.ca[:C], sa.cb[:C], sa.cc[:C], b.dgam_all[:C], b.dbet_all[:C])
+    eng.bn_coefs(sa.bstats, count, b.gamma_all[:C], sa.mean[:C], sa.invstd[:C], sa.ca[:C], sa.cb[:C], sa.cc[:C], b.dgam_all[:C], b.dbet_all[:C])
     ops.bn_bwd_apply(b.g, st.u, sa.ca, sa.cb, sa.cc, b.dconv, npix, C, code)
     for i, k in enumerate(st.sizes):
         conv, bn = module.convs[i][0], module.convs[i][1]

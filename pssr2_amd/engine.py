@@ -116,6 +116,9 @@ class Engine:
         self._convs = {}
         self.reducer = None          # pssr2_amd.distributed.GradReducer when data-parallel
         self._wepoch = [0]           # part of every packed-weight / folded-BatchNorm cache key (mark_weights_changed)
+        # sync_bn (model.sync_bn = True, data-parallel runs only): BatchNorm statistics over the GLOBAL batch -- the striped
+        # [sum, sum of squares] (forward) and [sum g, sum g*xhat] (backward) buffers of every BatchNorm are SUM-all-reduced before
+        # they are finalised, which is the reference's single-process semantics on N GPUs (off by default like DDP)
         self._flat_grad = None
         # weight-gradient launches (wgrad + partial-slab reduction) on a second HIP stream: nothing on the backward's
         # dependent chain waits for them, so they fill the chip while the chain runs its tiny BatchNorm-coefficient
@@ -444,10 +447,36 @@ class Engine:
             self._nbt_key = tuple(b.num_batches_tracked.data_ptr() for b in bns)
         self._nbt_flat.add_(1)
 
+    # ------------------------------------------------------------------ BatchNorm statistics (optionally over all ranks)
+    def _sync_world(self):
+        if not getattr(self.model, "sync_bn", False):
+            return 1
+        from . import distributed as D
+        return D.rank_world()[1]
+
+    def bn_stats_count(self, stats, count):
+        """Forward statistics of a BatchNorm about to be finalised: SUM over ranks under sync_bn.  Returns the sample count."""
+        world = self._sync_world()
+        if world > 1:
+            torch.distributed.all_reduce(stats)
+        return count * world
+
+    def bn_coefs(self, bstats, count, gamma, mean, invstd, ca, cb, cc, dgamma, dbeta):
+        """pssr_bn_bwd_coefs; under sync_bn the parameter gradients come from this rank's sums (the gradient all-reduce averages
+        them like every other gradient) and the input-gradient coefficients from the sums over all ranks."""
+        world = self._sync_world()
+        if world > 1:
+            ops.bn_bwd_coefs(bstats, count, gamma, mean, invstd, ca, cb, cc, dgamma, dbeta)
+            torch.distributed.all_reduce(bstats)
+            ops.bn_bwd_coefs(bstats, count * world, gamma, mean, invstd, ca, cb, cc, None, None)
+        else:
+            ops.bn_bwd_coefs(bstats, count, gamma, mean, invstd, ca, cb, cc, dgamma, dbeta)
+
     # ------------------------------------------------------------------ forward
     def _bn_forward(self, p, st, bn_module, count, train):
         if train:
             st.eval_key = None          # scale / shift now hold batch statistics, and the running statistics move
+            count = self.bn_stats_count(st.stats, count)
             ops.bn_finalize(st.stats, count, bn_module.weight, bn_module.bias, BN_EPS, BN_MOMENTUM,
                             bn_module.running_mean, bn_module.running_var, st.scale, st.shift, st.mean, st.invstd)
         else:
@@ -678,7 +707,7 @@ class Engine:
         self._before_write(dz)
         ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
         dgam, dbet = self._gbuf(bn_last.weight), self._gbuf(bn_last.bias)
-        ops.bn_bwd_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
+        self.bn_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
         grads[id(bn_last.weight)], grads[id(bn_last.bias)] = dgam, dbet
         grads[id(module.respass.bias)] = dbet               # d(respass bias) = sum dz = dbeta of the last BN (copied by _ready)
         self._before_write(dy)
@@ -693,7 +722,7 @@ class Engine:
                        aux=blk.y[k - 1], aux_scale=prev.scale, aux_shift=prev.shift, aux_mean=prev.mean, aux_invstd=prev.invstd,
                        stats=prev.bstats)
             dgam, dbet = self._gbuf(bn_prev.weight), self._gbuf(bn_prev.bias)
-            ops.bn_bwd_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
+            self.bn_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
             grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
             self._before_write(dy_alt)
             ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_alt, npix, blk.c, code)
@@ -773,7 +802,7 @@ class Engine:
         st.bstats.zero_()
         ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
-        ops.bn_bwd_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
+        self.bn_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
         self._ready(grads, list(m.norm.parameters()))
         return self._finish_backward(grads)

@@ -23,6 +23,9 @@ import torch
 from . import distributed as D
 
 
+LAST_TRAIN_STEPPER = None      # the stepper of the most recent train_paired call (bench.py reads its communication statistics)
+
+
 def enabled():
     return os.environ.get("PSSR_GRAPH", "1") != "0"
 
@@ -77,6 +80,16 @@ class TrainStepper:
         self.scale_dev = torch.ones(1, device=device) if scaler is not None else None
         self.cur = _Cursor(dataset, batch_size, capacity, device)
         self.graph, self.outs, self.eager_done = None, None, 0
+        self._reduced = False
+        # data-parallel: the step is captured as TWO graphs split where the gradients of the reconstruction head, the decoder and
+        # the deepest encoder block (the tail of the engine's flat buffer, ~85 % of a ResUNet's bytes) are final; their all-reduce is
+        # launched between the two replays and runs on RCCL's stream under the rest of the backward pass (PSSR_OVERLAP=0: one graph,
+        # one all-reduce after it)
+        self.split = self.world > 1 and os.environ.get("PSSR_OVERLAP", "1") != "0"
+        self.graph2, self.split_at = None, 0
+        self.comm_events = [] if os.environ.get("PSSR_COMM_STATS") == "1" else None     # (after graph 2, after the all-reduces) per step
+        global LAST_TRAIN_STEPPER
+        LAST_TRAIN_STEPPER = self
 
     def begin_epoch(self, order):
         self.n = self.cur.load(order)
@@ -105,8 +118,9 @@ class TrainStepper:
         eng, opt = self.engine, self.optim
         if self.in_graph_optim:
             return
-        if self.world > 1:
+        if self.world > 1 and not self._reduced:
             torch.distributed.all_reduce(eng._flat_grad)
+        self._reduced = False
         eng.publish_grads()             # a replayed backward wrote the flat buffer but ran no Python
         if self.scaler is not None:
             if self.world > 1:
@@ -141,13 +155,86 @@ class TrainStepper:
             return out
         if self.graph is None:
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.outs = self._body()
-            self.graph = g
-        self.graph.replay()
+            if self.split:
+                try:
+                    self._capture_split()
+                except Exception as e:                          # any capture problem: one graph + one all-reduce after it
+                    if self.rank == 0:
+                        print(f"[pssr2_amd] split capture unavailable ({type(e).__name__}: {e}); all-reduce after the backward graph", flush=True)
+                    self.split, self.graph, self.graph2 = False, None, None
+                    torch.cuda.synchronize()
+            if self.graph is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.outs = self._body()
+                self.graph = g
+        if self.graph2 is not None:
+            flat, a0 = self.engine._flat_grad, self.split_at
+            self.graph.replay()
+            h1 = torch.distributed.all_reduce(flat[a0:], async_op=True)      # waits for graph 1 on RCCL's stream, runs under graph 2
+            self.graph2.replay()
+            h2 = torch.distributed.all_reduce(flat[:a0], async_op=True)
+            if self.comm_events is not None:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+            h1.wait(), h2.wait()
+            if self.comm_events is not None:
+                eb.record()
+                self.comm_events.append((ea, eb))
+            self._reduced = True
+        else:
+            self.graph.replay()
         self._after()
         return self.outs
+
+    def _capture_split(self):
+        """forward + loss + the first part of the backward | the rest of the backward, as two hipGraphs sharing one memory pool.  The
+        engine's backward is driven directly (d loss / d output from autograd.grad) so that the capture can switch graphs inside it."""
+        eng = self.engine
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        state = {"g": None}
+
+        def switch():
+            g1.capture_end()
+            state["g"] = None
+            g2.capture_begin(pool=pool)
+            state["g"] = g2
+        with torch.cuda.stream(cap):
+            try:
+                g1.capture_begin(pool=pool)
+                state["g"] = g1
+                hr, lr = self.dataset.device_batch(self.cur.next_rows())
+                hr_hat = self.model(lr)
+                if self.clamp:
+                    hr_hat = torch.clamp(hr_hat, 0, self.image_range)
+                loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
+                (dout,) = torch.autograd.grad(loss * self.scale_dev if self.scale_dev is not None else loss, hr_hat)
+                eng.backward(dout, split_cb=switch)
+                if state["g"] is not g2:
+                    raise RuntimeError("the engine's backward did not reach its split point")
+                g2.capture_end()
+                state["g"] = None
+            except Exception:
+                if state["g"] is not None:          # leave no stream in capture mode behind
+                    try:
+                        state["g"].capture_end()
+                    except Exception:
+                        pass
+                raise
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        self.graph, self.graph2, self.split_at = g1, g2, eng.grad_split_offset()
+        self.outs = (hr, lr, hr_hat.detach(), loss.detach())
+
+    def exposed_comm_ms(self, last=None):
+        """Mean time per step the launch stream sat waiting for the gradient all-reduces after the backward graph had finished
+        (PSSR_COMM_STATS=1): the part of the communication that the backward pass did not hide."""
+        ev = self.comm_events or []
+        ev = ev[-last:] if last else ev
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
     def _leave_graph(self):
         """Control goes back to eager code (or to another graph): its caches must not trust parameter versions."""

@@ -558,7 +558,7 @@ class RDEngine(Engine):
         stn.bstats.zero_()
         ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
-        ops.bn_bwd_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)
+        self.bn_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
         self._ready(grads, list(m.norm.parameters()))
         return self._finish_backward(grads)
