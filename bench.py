@@ -167,13 +167,13 @@ def cpu_baseline():
                 c1_train_tiles_per_s=round(c1, 3), c2_infer_tiles_per_s=round(inf, 3))
 
 
-def make_tiles(n, res, channels, rank):
+def make_tiles(n, res, channels, rank, max_workers=16):
     """n seeded synthetic-EM uint8 tiles [n, channels, res, res], generated by a process pool before the GPU is touched."""
     import numpy as np
     from concurrent.futures import ProcessPoolExecutor
     from functools import partial
     from pssr2_amd.data import synthetic_em_tile
-    workers = max(1, min(16, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+    workers = max(1, min(max_workers, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     idx = [rank * 1000003 + i for i in range(n)]
     if workers == 1 or n < 64:
         tiles = [synthetic_em_tile(i, res, channels) for i in idx]
@@ -215,6 +215,7 @@ def main():
                     help="infer: predict_images at --batch; sheet: BASELINE config 5 (4096^2 LR sheet, 128^2 tiles, overlap 32, batch 128)")
     ap.add_argument("--model", default="resunet", choices=["resunet", "rdresunet"])
     ap.add_argument("--crappifier", default="gaussian", choices=["gaussian", "poisson"])
+    ap.add_argument("--tile-workers", type=int, default=16, help="processes generating the synthetic tiles (1 under rocprofv3: no forks behind the profiler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the infer / sheet / f32 legs that follow the headline region")
     ap.add_argument("--no-graph", action="store_true", help="PSSR_GRAPH=0: every kernel launched from Python by the drivers")
@@ -230,7 +231,7 @@ def main():
     hr_res = args.lr_res * 4
     n_tiles = args.tiles if args.mode != "sheet" else 0
     need = (args.warmup + args.steps) * args.batch
-    tiles_np = make_tiles(n_tiles, hr_res, args.channels, rank_env) if n_tiles else None      # before CUDA: the pool forks
+    tiles_np = make_tiles(n_tiles, hr_res, args.channels, rank_env, args.tile_workers) if n_tiles else None      # before CUDA: the pool forks
 
     from pssr2_amd import distributed as D
     force_dev = os.environ.get("PSSR_BENCH_FORCE_DEVICE")       # rehearsal knob: several gloo ranks on ONE card

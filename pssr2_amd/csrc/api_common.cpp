@@ -29,6 +29,7 @@ const Entry kEntries[] = {
     {"IGEMM_BIG", &PssrTunables::igemm_big, 1, 0, 2},
     {"IGEMM_V2", &PssrTunables::igemm_v2, 0, 0, 2},
     {"IGEMM_V3", &PssrTunables::igemm_v3, 1, 0, 2},
+    {"IGEMM_V3_64", &PssrTunables::igemm_v3_64, 1, 0, 1},
     {"IGEMM_DBG", &PssrTunables::igemm_dbg, 0, 0, 255},
     {"IGEMM_KSPLIT", &PssrTunables::igemm_ksplit, 384, 1, 1 << 20},
     {"CONV_EPI8", &PssrTunables::conv_epi8, 1, 0, 1},

@@ -56,14 +56,19 @@ template <int BN, int GEO> struct Cfg {
     static constexpr int RED_BYTES = 4 * BN * 2 * 4;
     static constexpr int MAIN_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-    static constexpr bool PERM = false;     // MFMA row r of a 32-row tile is pixel r of the tile's pixel order
+    static constexpr int PERM = 0;          // MFMA row r of a 32-row tile is pixel r of the tile's pixel order
 };
 
 // output pixel (within the workgroup's tile) of accumulator row `row` (0 .. WM*32-1) of row tile mi.  C::PERM (conv_v3.h): the
 // two image rows of a 32-row tile are interleaved so that every ds_read_b128 lane group reads one image row
 template <class C> __device__ __forceinline__ int epi_pixel(int row, int mi) {
     int r = row & 31;
-    if constexpr (C::PERM) r = (((r >> 4) ^ (((r & 15) >= 4 && (r & 15) < 12) ? 1 : 0)) << 4) | (r & 15);
+    if constexpr (C::PERM != 0) {
+        const int rx = r & 15, ry = (r >> 4) ^ ((rx >= 4 && rx < 12) ? 1 : 0);
+        if constexpr (C::PERM == 2)          // 16 rows x 32 columns, wave = 4 image rows, row tile = (row pair mi >> 1, column half mi & 1)
+            return (((row >> 5) * 4 + (mi >> 1) * 2 + ry) << 5) | ((mi & 1) << 4) | rx;
+        r = (ry << 4) | rx;
+    }
     return (row >> 5) * C::MI * 32 + mi * 32 + r;
 }
 
@@ -801,7 +806,7 @@ template <int BN, int TAPS> struct Cfg2 {
     static constexpr int RING = 2;                                                  // weight stages resident in LDS
     static constexpr int MAIN_BYTES = 2 * A_BYTES + RING * B_BYTES;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-    static constexpr bool PERM = false;
+    static constexpr int PERM = 0;
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -1138,15 +1143,17 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
 }
 
 // v3 takes the 3x3 layers (16-bit storage) whose images hold a 16x16 tile; g_v3_mode 0 disables it (tests run both loops)
-template <typename T>
+template <typename T, int BN>
 bool use_v3(const ConvArgs& a) {
     if constexpr (sizeof(T) != 2) return false;
     const int mode = pssr_tunables().igemm_v3;
-    if (!mode || a.taps[0] != 9 || a.W < 16 || a.H < 16 || a.prologue == PSSR_PRO_GELU || a.epi == PSSR_EPI_FINAL || !a.epi8) return false;
+    constexpr int TW = BN == 128 ? 16 : 32;
+    if (BN == 64 && !pssr_tunables().igemm_v3_64) return false;
+    if (!mode || a.taps[0] != 9 || a.W < TW || a.H < 16 || a.prologue == PSSR_PRO_GELU || a.epi == PSSR_EPI_FINAL || !a.epi8) return false;
     if (mode == 2) return true;             // tests: whenever the shape allows
     // two workgroups per CU cover each other's barriers, pipeline fill and epilogue: with fewer than ~1.5 tiles per CU the
     // 128-pixel loop (twice the workgroups) measured faster (32^2 x 256 and 16^2 x 512 layers at batch 32: 828 vs 757, 713 vs 643 TFLOP/s)
-    const long blocks = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.N * cdiv(a.cout, 128);
+    const long blocks = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.N * cdiv(a.cout, BN);
     return blocks >= 384;
 }
 
@@ -1267,7 +1274,7 @@ int launch_geo(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 int launch_bn(const ConvArgs& a, hipStream_t s) {
     if (a.cout > 64) {
-        if constexpr (sizeof(T) == 2) { if (use_v3<T>(a)) return launch3_t<T, 128>(a, s); }
+        if constexpr (sizeof(T) == 2) { if (use_v3<T, 128>(a)) return launch3_t<T, 128>(a, s); }
         if (use_v2<T, 128>(a)) return a.taps[0] == 9 ? launch2_t<T, 128, 9>(a, s) : launch2_t<T, 128, 1>(a, s);
         if constexpr (sizeof(T) == 2) {
             if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
@@ -1275,6 +1282,7 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
         return launch_geo<T, 128>(a, s);
     }
     if (a.cout > 32) {
+        if constexpr (sizeof(T) == 2) { if (use_v3<T, 64>(a)) return launch3_t<T, 64>(a, s); }
         if (use_v2<T, 64>(a)) return a.taps[0] == 9 ? launch2_t<T, 64, 9>(a, s) : launch2_t<T, 64, 1>(a, s);
         return launch_geo<T, 64>(a, s);
     }

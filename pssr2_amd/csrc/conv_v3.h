@@ -31,26 +31,40 @@
 namespace {
 
 template <int BN> struct Cfg3 {
-    static_assert(BN == 128, "v3 tile: 256 pixels x 128 channels");
-    static constexpr int TWL = 4, THL = 4, TW = 16, TH = 16, NI = 1;
-    static constexpr int WM = 2, WN = 2, MI = 4, NJ = BN / 64, MP = 256;
-    static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2);
-    static constexpr int PLANE = HPI * 16, A_BYTES = 2 * PLANE;          // 5184 (= 40 * 128 + 64: the two halves of a commit store hit different banks), 10368
-    static constexpr int A_ITEMS = (2 * HPI + 255) / 256;                 // 3
-    static constexpr int B_SLICE = BN * 32, B_STAGE = 3 * B_SLICE;        // 4096, 12288
-    static constexpr int B0 = 2 * A_BYTES;                                // 20736
-    static constexpr int MAIN_BYTES = B0 + 3 * B_STAGE;                   // 57600
+    static_assert(BN == 128 || BN == 64, "v3 tiles: 16x16 pixels x 128 channels, or 16x32 pixels x 64 channels");
+    // BN = 128: 16 x 16 pixels, waves 2 (pixels) x 2 (channels); BN = 64: 16 rows x 32 columns, the four waves stacked along the rows.
+    // Either way a wave owns 128 pixels x 64 channels = 4 x 2 accumulator tiles and runs the same stage code.
+    static constexpr int TWL = BN == 128 ? 4 : 5, THL = 4, TW = 1 << TWL, TH = 16, NI = 1;
+    static constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM, MI = 4, NJ = 2, MP = TW * TH;
+    static constexpr int HW2 = TW + 2, HPI = (TH + 2) * HW2;
+    static constexpr int PLANE = HPI * 16, A_BYTES = 2 * PLANE;          // 5184 / 9792: both = 64 mod 128, so the two halves of a commit store hit different banks
+    static_assert(PLANE % 128 == 64, "plane size");
+    static constexpr int A_ITEMS = (2 * HPI + 255) / 256;                 // 3 / 5
+    static constexpr int B_SLICE = BN * 32, B_STAGE = 3 * B_SLICE;        // 4096, 12288 / 2048, 6144
+    static constexpr int PPS = B_SLICE / 1024, NPIECE = 3 * PPS;          // 1-KiB LDS-DMA pieces per slice / per stage
+    static constexpr int NP = (NPIECE + 3) / 4;                           // pieces a wave issues per stage (3 / 2; BN = 64: two of the 8 are duplicates)
+    static constexpr int B0 = 2 * A_BYTES;
+    static constexpr int MAIN_BYTES = B0 + 3 * B_STAGE;                   // 57600 / 57600
     static constexpr int E_BYTES = WM * 32 * BN * 4, RED_BYTES = 4 * BN * 2 * 4;
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-    static constexpr bool PERM = true;
+    static constexpr int PERM = BN == 128 ? 1 : 2;
+    // byte offset (within a plane) of accumulator row tile mi of a wave: image rows 2 mi (BN = 128); row pair mi >> 1, column half mi & 1 (BN = 64)
+    static constexpr int AMI1 = BN == 128 ? 2 * HW2 * 16 : 16 * 16;
+    static constexpr int AMI2 = BN == 128 ? 4 * HW2 * 16 : 2 * HW2 * 16;
+    static constexpr int AMI3 = BN == 128 ? 6 * HW2 * 16 : 2 * HW2 * 16 + 16 * 16;
+    static constexpr int ROWB = HW2 * 16;                                  // bytes per halo row of a plane (one kernel row down)
 };
 
 // ---- the multiply of one stage as one asm statement.
 // operands: %0-%7 accumulators [mi*2+nj]; %8-%13 fragment set 0 (A0-A3, B0, B1); %14-%19 set 1; %20 image address
-// (per-wave base incl. the lane's half plane); %21 weight address; %22 image offset (buffer + kernel row); %23 weight
-// offset (ring slot)
-#define V3_RA(D, MI_, KX) "ds_read_b128 %" #D ", %20 offset:%c22+" #MI_ "*576+" #KX "*16\n\t"
-#define V3_RB(D, NJ_, KX) "ds_read_b128 %" #D ", %21 offset:%c23+" #KX "*4096+" #NJ_ "*1024\n\t"
+// (per-wave base incl. the lane's half plane); %21 weight address; %22 image offset (kernel row); %23-%26 offsets of the
+// wave's row tiles 0-3 (%23 = 0); %27 weight offset (ring slot); %28 bytes of one weight slice (tap)
+#define V3_AMI_0 "%c23"
+#define V3_AMI_1 "%c24"
+#define V3_AMI_2 "%c25"
+#define V3_AMI_3 "%c26"
+#define V3_RA(D, MI_, KX) "ds_read_b128 %" #D ", %20 offset:%c22+" V3_AMI_##MI_ "+" #KX "*16\n\t"
+#define V3_RB(D, NJ_, KX) "ds_read_b128 %" #D ", %21 offset:%c27+" #KX "*%c28+" #NJ_ "*1024\n\t"
 #define V3_MM(OP, ACC, A, B) OP " %" #ACC ", %" #A ", %" #B ", %" #ACC "\n\t"
 #define V3_READ0(KXA, KXB) V3_RA(8, 0, KXA) V3_RB(12, 0, KXB) V3_RB(13, 1, KXB) V3_RA(9, 1, KXA) V3_RA(10, 2, KXA) V3_RA(11, 3, KXA)
 // 8 MFMAs on set 0 with the reads of tap KX into set 1 between them (and vice versa)
@@ -75,7 +89,7 @@ template <int BN> struct Cfg3 {
           "+v"(acc[3][0]), "+v"(acc[3][1]),                                                                               \
           "=&v"(fr[0]), "=&v"(fr[1]), "=&v"(fr[2]), "=&v"(fr[3]), "=&v"(fr[4]), "=&v"(fr[5]),                              \
           "=&v"(fr[6]), "=&v"(fr[7]), "=&v"(fr[8]), "=&v"(fr[9]), "=&v"(fr[10]), "=&v"(fr[11])                             \
-        : "v"(a_addr), "v"(b_addr), "i"(AOFF), "i"(BOFF)                                                                  \
+        : "v"(a_addr), "v"(b_addr), "i"(AOFF), "i"(0), "i"(C::AMI1), "i"(C::AMI2), "i"(C::AMI3), "i"(BOFF), "i"(C::B_SLICE)   \
         : "memory"
 
 template <typename T> struct V3Op;
@@ -83,14 +97,14 @@ template <> struct V3Op<bf16_t> { static constexpr bool BF = true; };
 template <> struct V3Op<f16_t> { static constexpr bool BF = false; };
 
 // one kernel row (3 taps) of the chunk staged in image `a_addr`, weights in ring slot BOFF
-template <typename T, int AOFF, int BOFF>
+template <typename T, class C, int AOFF, int BOFF>
 __device__ __forceinline__ void v3_row(f32x16 (&acc)[4][2], unsigned a_addr, unsigned b_addr) {
     u32x4 fr[12];
     if constexpr (V3Op<T>::BF) asm volatile(V3_ROW_TEXT("v_mfma_f32_32x32x16_bf16") V3_OPERANDS(AOFF, BOFF));
     else asm volatile(V3_ROW_TEXT("v_mfma_f32_32x32x16_f16") V3_OPERANDS(AOFF, BOFF));
 }
 // the centre tap only (1x1 second source, staged in the same halo geometry); the ring slot is part of b_addr
-template <typename T, int AOFF>
+template <typename T, class C, int AOFF>
 __device__ __forceinline__ void v3_one(f32x16 (&acc)[4][2], unsigned a_addr, unsigned b_addr) {
     u32x4 fr[12];
     if constexpr (V3Op<T>::BF) asm volatile(V3_ONE_TEXT("v_mfma_f32_32x32x16_bf16") V3_OPERANDS(AOFF, 0));
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int h = lane >> 5, r = lane & 31;
 
     const int bid = blockIdx.x;
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
     const int tile_y = tmi % p.tiles_y;
     const int img0 = tmi / p.tiles_y;
-    const int x0 = tile_x << 4, y0 = tile_y << 4, n0 = tn * BN;
+    const int x0 = tile_x << C::TWL, y0 = tile_y << 4, n0 = tn * BN;
 
     // ---- halo staging descriptors (the same pixels for every chunk): item = (halo pixel, 16-byte half)
     const long img_base = (long)img0 * p.H * p.W;
@@ -149,15 +163,23 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     // ---- fragment addresses: image row tile mi / tap and weight tile nj / tap are immediates
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int rx = r & 15, ry = (r >> 4) ^ ((rx >= 4 && rx < 12) ? 1 : 0);
-    const unsigned a_addr0 = lds0 + h * C::PLANE + ((wm * 8 + ry) * C::HW2 + rx) * 16;
+    const int wrow = BN == 128 ? wm * 8 : wave * 4;                      // first image row of the wave's 128 pixels
+    const unsigned a_addr0 = lds0 + h * C::PLANE + ((wrow + ry) * C::HW2 + rx) * 16;
     const unsigned b_addr0 = lds0 + C::B0 + (wn * 64 + r) * 32 + ((h ^ ((r >> 3) & 1)) << 4);
 
     // ---- LDS-DMA pieces of this wave: piece q = wave + 4 j of a 3-slice stage = (slice q >> 2, KiB q & 3 of the slice)
     const int tap_stride = p.n_pad * 32;
-    unsigned d_voff[3];
+    // piece q = (wave + 4 j) mod NPIECE of a 3-slice stage = (slice q / PPS, KiB q % PPS of the slice); BN = 64 has 6 pieces for 8 issue
+    // slots: two are issued twice (same bytes to the same place), so that every wave has the same number of operations in flight
+    unsigned d_voff[C::NP];
+    unsigned d_loff[C::NP];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) d_voff[j] = (unsigned)(j * tap_stride + wave * 1024 + lane * 16);     // q >> 2 == j, q & 3 == wave
-    const unsigned d_lds = lds0 + C::B0 + wave * 1024;                                  // + slot * B_STAGE + j * B_SLICE
+    for (int j = 0; j < C::NP; ++j) {
+        const int q = (wave + 4 * j) % C::NPIECE;
+        d_voff[j] = (unsigned)((q / C::PPS) * tap_stride + (q % C::PPS) * 1024 + lane * 16);
+        d_loff[j] = (unsigned)(q * 1024);
+    }
+    const unsigned d_lds = lds0 + C::B0;                                  // + slot * B_STAGE + piece * 1024
     const char* const w0n = (const char*)p.w[0] + (long)n0 * 32;
     const char* const w1n = (const char*)p.w[1] + (long)n0 * 32;
 
@@ -256,17 +278,24 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
         const unsigned dl_ = d_lds + (unsigned)(SLOT) * C::B_STAGE;                                               \
         if (s_ < 3 * (ce - cb)) {                                                                                 \
             const char* src_ = w0n + (long)((cb * 3 + s_) * 3) * tap_stride;       /* chunk cb + s/3, kernel row s % 3 */ \
-            v3_dma(dl_, d_voff[0], src_);                                                                         \
-            v3_dma(dl_ + C::B_SLICE, d_voff[1], src_);                                                            \
-            v3_dma(dl_ + 2 * C::B_SLICE, d_voff[2], src_);                                                        \
-        } else {                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < C::NP; ++j)                                                     \
+                v3_dma(__builtin_amdgcn_readfirstlane(dl_ + d_loff[j]), d_voff[j], src_);                         \
+        } else {      /* one slice: PPS pieces; waves past them re-issue piece 0 */                                \
             const char* src_ = w1n + (long)(s_ - 3 * (ce - cb)) * tap_stride;                                     \
-            v3_dma(dl_, d_voff[0], src_);                                                                         \
+            const unsigned pq_ = (unsigned)(wave % C::PPS);                                                       \
+            v3_dma(dl_ + pq_ * 1024, pq_ * 1024 + lane * 16, src_);                                               \
         }                                                                                                         \
     }
     // end of a stage: the next stage's weights (everything but the youngest N vector-memory operations of this wave) have
     // landed and this wave's LDS stores are done; then all waves meet
-#define V3_END(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define V3_END_(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // KIND 0: everything landed; 1: the youngest NP operations (one stage of weights) stay in flight; 2: NP + A_ITEMS (+ the next image)
+#define V3_END(KIND)                                                                                              \
+    {                                                                                                             \
+        if constexpr ((KIND) == 0) { V3_END_(0); }                                                                \
+        else if constexpr (BN == 128) { if constexpr ((KIND) == 1) { V3_END_(3); } else { V3_END_(6); } }         \
+        else { if constexpr ((KIND) == 1) { V3_END_(2); } else { V3_END_(7); } }                                  \
+    }
 
     if (nst > 0) {
         const int ns0 = 3 * (ce - cb);      // stages of source 0
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
         if (nst > 1) V3_DMA_B(1, 1)
         __syncthreads();                    // prologue table
         V3_COMMIT_A(0)
-        if (ns0 > 1) { V3_END(3); }         // stage 1 is a 3-piece stage: it stays in flight
+        if (ns0 > 1) { V3_END(1); }         // stage 1 is a full stage: it stays in flight
         else { V3_END(0); }
 
         V3_STAMP(4)
@@ -290,30 +319,30 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
             if (more) V3_LOAD_A(k + 1)
             V3_DMA_B(s + 2, 2)
             V3_STAMP(0)
-            if (!(p.dbg & 2)) v3_row<T, 0 * 288, 0 * C::B_STAGE>(acc, a_cur, b_addr0);
+            if (!(p.dbg & 2)) v3_row<T, C, 0 * C::ROWB, 0 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
             V3_STAMP(1)
-            if (more) { V3_END(6); } else { V3_END(3); }
+            if (more) { V3_END(2); } else { V3_END(1); }
             V3_STAMP(3)
             ++s;
             // ---- kernel row 1
             if (s + 2 < nst) V3_DMA_B(s + 2, 0)
             V3_STAMP(0)
-            if (!(p.dbg & 2)) v3_row<T, 1 * 288, 1 * C::B_STAGE>(acc, a_cur, b_addr0);
+            if (!(p.dbg & 2)) v3_row<T, C, 1 * C::ROWB, 1 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
             V3_STAMP(1)
-            if (more0) { V3_END(3); } else { V3_END(0); }
+            if (more0) { V3_END(1); } else { V3_END(0); }
             V3_STAMP(3)
             ++s;
             // ---- kernel row 2: commits the next image
             if (s + 2 < nst) V3_DMA_B(s + 2, 1)
             V3_STAMP(0)
-            if (!(p.dbg & 2)) v3_row<T, 2 * 288, 2 * C::B_STAGE>(acc, a_cur, b_addr0);
+            if (!(p.dbg & 2)) v3_row<T, C, 2 * C::ROWB, 2 * C::B_STAGE>(acc, a_cur, b_addr0);
             __builtin_amdgcn_sched_barrier(0);
             V3_STAMP(1)
             if (more) V3_COMMIT_A(k + 1)
             V3_STAMP(2)
-            if (more0) { V3_END(3); } else { V3_END(0); }
+            if (more0) { V3_END(1); } else { V3_END(0); }
             V3_STAMP(3)
             ++s;
             a_cur = a_addr0 + (unsigned)((k + 1) & 1) * C::A_BYTES;
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
             const bool more = k + 1 < nimg;
             if (more) V3_LOAD_A(k + 1)
             if (s + 2 < nst) V3_DMA_B(s + 2, (slot + 2) % 3)
-            v3_one<T, 288>(acc, a_cur, b_addr0 + (unsigned)slot * C::B_STAGE);
+            v3_one<T, C, C::ROWB>(acc, a_cur, b_addr0 + (unsigned)slot * C::B_STAGE);
             __builtin_amdgcn_sched_barrier(0);
             if (more) V3_COMMIT_A(k + 1)
             V3_END(0);
@@ -337,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
 #undef V3_COMMIT_A
 #undef V3_DMA_B
 #undef V3_END
+#undef V3_END_
 #undef V3_STAMP
 #ifdef PSSR_V3_STAMPS
     if (p.stamps && lane == 0) {

@@ -33,6 +33,11 @@ V3_CASES = [
     (2, 256, 128, 16, 16, 0),     # few tiles, 16 chunks: split-K + finish kernel
     (2, 208, 128, 16, 16, 48),    # split-K with an uneven split (13 chunks) and the second source riding with the last slice
     (1, 1024, 128, 16, 16, 0),    # 64 chunks: the BatchNorm table of 1024 channels behind the tiles, split-K 8
+    # 64-channel tiles: 16 rows x 32 columns of pixels, the four waves stacked along the rows
+    (2, 64, 64, 32, 64, 0),       # 4 chunks, 4 full tiles per image
+    (1, 96, 64, 16, 32, 0),       # one tile, 6 chunks
+    (3, 32, 48, 24, 40, 16),      # partial tiles in both directions, ragged channel tile, second source
+    (2, 256, 64, 16, 32, 0),      # split-K
 ]
 
 
@@ -82,7 +87,7 @@ def test_v3_forward(case, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(2, 128, 128, 32, 32), (1, 64, 192, 24, 40), (2, 512, 256, 16, 16)])
+@pytest.mark.parametrize("case", [(2, 128, 128, 32, 32), (1, 64, 192, 24, 40), (2, 512, 256, 16, 16), (2, 128, 64, 32, 32), (1, 1024, 64, 16, 64)])
 def test_v3_dgrad_mask_stats(case, dt):
     """Input gradient through v3 (GEMM-K = cout, GEMM-N = cin) with the ReLU-mask + BatchNorm-backward statistics epilogue,
     and the plain dgrad with a 1x1 second source (the first conv + residual 1x1 of a block)."""
