@@ -34,6 +34,7 @@ const Entry kEntries[] = {
     {"IGEMM_KSPLIT", &PssrTunables::igemm_ksplit, 384, 1, 1 << 20},
     {"CONV_EPI8", &PssrTunables::conv_epi8, 1, 0, 1},
     {"WGRAD_LEAN", &PssrTunables::wgrad_lean, 1, 0, 1},
+    {"WGRAD_X2", &PssrTunables::wgrad_x2, 0, 0, 1},
     {"WGRAD_BLOCKS", &PssrTunables::wgrad_blocks, 256, 1, 1 << 20},
     {"WGRAD_BLOCKS_1X1", &PssrTunables::wgrad_blocks_1x1, 512, 1, 1 << 20},
     {"DWCONV_TILE", &PssrTunables::dwconv_tile, 1, 0, 1},

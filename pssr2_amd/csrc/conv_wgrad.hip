@@ -24,6 +24,8 @@ struct WgradArgs {
     float* dw;                                             // [parts][cout][taps][cin_pad] f32 (parts == 0: one slab, atomics)
     int co_tiles, ci_tiles;
     int parts; long part_stride;
+    unsigned* stamps;                                      // diagnostic build (-DPSSR_WG_STAMPS) only: per-(workgroup, wave) phase cycle sums
+    int dbg;                                               // IGEMM_DBG bits (timing experiments): 16 skip the multiply, 32 skip the tile staging
 };
 
 template <int GEO> struct WGeo;
@@ -296,6 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Dy = smem;
     char* Ah = smem + DY_BYTES;
+#ifdef PSSR_WG_STAMPS
+    unsigned long long st_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cosub = wave % CO_S, cisub = wave / CO_S;
@@ -403,31 +409,363 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
         }                                                                                                         \
     }
 
+#ifdef PSSR_WG_STAMPS
+    unsigned long long st_prev = 0;
+    unsigned st_sum[6] = {0, 0, 0, 0, 0, 0};
+#define WG_STAMP(I)                                                                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if ((I) >= 0) st_sum[(I) < 0 ? 0 : (I)] += (unsigned)(t_ - st_prev);                                      \
+        st_prev = t_;                                                                                             \
+    }
+#else
+#define WG_STAMP(I)
+#endif
     int tile = blockIdx.x;
+    WG_STAMP(-1)
+#ifdef PSSR_WG_STAMPS
+    const unsigned st_pro = (unsigned)(st_prev - st_t0);
+#endif
     if (tile < p.n_tiles) WG_ISSUE(tile)
+    const bool first_only = p.dbg & 32;
     for (; tile < p.n_tiles; tile += p.split) {
-        WG_COMMIT()
+        WG_STAMP(5)
+#ifdef PSSR_WG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segment 0 = exposed load latency
+#endif
+        WG_STAMP(0)
+        if (!first_only || tile == (int)blockIdx.x) WG_COMMIT()
+        WG_STAMP(1)
         __syncthreads();
+        WG_STAMP(2)
         const int nt = tile + p.split;
-        if (nt < p.n_tiles) WG_ISSUE(nt)
+        if (nt < p.n_tiles && !first_only) WG_ISSUE(nt)
+        WG_STAMP(3)
 
         // ---- multiply: 8 k-steps of 16 pixels x taps; addresses = lane base + compile-time offsets
+        if (p.dbg & 16) {
+        } else if constexpr (GEO == 0 && TAPS == 9) {
+            // a k-step is one 16-pixel tile row, so the input fragment of tap (ky, kx) at k-step s is the fragment of halo row s + ky
+            // at column offset kx: each halo row is fetched once (3 fragments) into a 3-row register window and multiplied by
+            // the dy fragments of the three k-steps that see it -- 4 fragment fetches per 9 MFMAs instead of 10 (the LDS read
+            // port, not the matrix pipe, bounded the 10-fetch loop: 20 x 512 B per 9 x 8 clocks per CU > 128 B/clk)
+            u32x4 win[3][3];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);
-            const int hs = wg_halo_pix<GEO>(s * 16) * ROWB;
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int ky = (TAPS == 9) ? t / 3 : 1, kx = (TAPS == 9) ? t % 3 : 1;
-                const int toff = (ky * HW2 + kx) * ROWB + hs;
-                const u32x4 bf = Frag16::load(ah_rd0 + toff, ah_rd1 + toff);
-                X::mma(acc[t], af, bf);
+                for (int kx = 0; kx < 3; ++kx) win[r][kx] = Frag16::load(ah_rd0 + (r * HW2 + kx) * ROWB, ah_rd1 + (r * HW2 + kx) * ROWB);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    win[(s + 2) % 3][kx] = Frag16::load(ah_rd0 + ((s + 2) * HW2 + kx) * ROWB, ah_rd1 + ((s + 2) * HW2 + kx) * ROWB);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) X::mma(acc[t], af, win[(s + t / 3) % 3][t % 3]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);
+                const int hs = wg_halo_pix<GEO>(s * 16) * ROWB;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = (TAPS == 9) ? t / 3 : 1, kx = (TAPS == 9) ? t % 3 : 1;
+                    const int toff = (ky * HW2 + kx) * ROWB + hs;
+                    const u32x4 bf = Frag16::load(ah_rd0 + toff, ah_rd1 + toff);
+                    X::mma(acc[t], af, bf);
+                }
             }
         }
+        WG_STAMP(4)
         __syncthreads();
     }
+    WG_STAMP(5)
 #undef WG_ISSUE
 #undef WG_COMMIT
+#undef WG_STAMP
+
+    const int kcol = k0 + cisub * 32 + (lane & 31);
+    if (kcol < p.cin_pad) {
+        float* dst = p.dw + (p.parts > 0 ? (long)blockIdx.x * p.part_stride : 0L);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + cosub * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (n < p.cout) {
+                    float* qd = dst + ((long)n * TAPS + t) * p.cin_pad + kcol;
+                    if (p.parts > 0) *qd = acc[t][e];
+                    else atomicAdd(qd, acc[t][e]);
+                }
+            }
+        }
+    }
+#ifdef PSSR_WG_STAMPS
+    if (p.stamps) {
+        unsigned long long t1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        if (lane == 0) {
+            unsigned* q = p.stamps + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            for (int i = 0; i < 6; ++i) q[i] = st_sum[i];
+            q[6] = ((p.n_tiles - (int)blockIdx.x + p.split - 1) / p.split) | (st_pro << 8);
+            q[7] = (unsigned)(t1 - st_prev);
+        }
+    }
+#endif
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Two-group build of the lean 3x3 kernel (16x8-pixel tiles).  Phase stamps of the kernel above at one workgroup per CU (one
+// wave per SIMD): of ~6000 clocks per pixel tile only ~2580 are the 72 MFMAs; ~1830 are the commit (BatchNorm/ReLU prologue +
+// LDS writes) and ~1140 the issue of the next tile (tile coordinates by division, descriptors), and nothing overlaps them.
+// Here a workgroup is 8 waves = two groups of 4; both groups accumulate the SAME slab over alternate pixel tiles of the
+// workgroup's subset, one phase apart:   A: commit+issue | multiply | commit+issue | ...
+//                                        B:      -       | commit+issue | multiply | ...
+// so each SIMD holds one wave in its MFMA block and one in its vector/LDS-write block.  Each group has its own LDS tile;
+// the phases are separated by workgroup barriers.  At the end group B hands its accumulators to group A through LDS (3 taps
+// per round), so the partial-slab traffic stays that of 256 workgroups.  Tile coordinates advance incrementally (no division).
+template <typename T, int CO_T, int CI_T>
+__global__ __launch_bounds__(512, 1) void conv_wgrad16x2_kernel(const WgradArgs p) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2, "16-bit types");
+    constexpr int GEO = 0, TAPS = 9, EPS = 8, ESZ = 2;
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 1;
+    constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI;
+    constexpr int ROWB = 64, PPS = 4;
+    constexpr int CO_S = CO_T / 32, CI_S = CI_T / 32;
+    static_assert(CO_S * CI_S == 4, "one (cout sub, cin sub) pair per wave");
+    constexpr int DY_BYTES = CO_S * 128 * ROWB, AH_BYTES = CI_S * HP * ROWB, GRP_BYTES = DY_BYTES + AH_BYTES;
+    constexpr int DY_PPP = CO_S * PPS, AH_PPP = CI_S * PPS;
+    constexpr int DY_PIECES = 128 * DY_PPP, AH_PIECES = HP * AH_PPP;
+    constexpr int DY_ITEMS = DY_PIECES / 256, AH_ITEMS = (AH_PIECES + 255) / 256;
+    static_assert(DY_PIECES % 256 == 0 && 256 % DY_PPP == 0 && 256 % AH_PPP == 0 && AH_ITEMS <= 16, "item geometry");
+    static_assert(2 * GRP_BYTES >= 12 * 256 * 16, "hand-over buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef X2_GRP0
+    const int grp = 0;
+#else
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+#endif
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+#ifdef X2_SAMELDS
+    char* const Dy = smem;
+#else
+    char* const Dy = smem + grp * GRP_BYTES;
+#endif
+    char* const Ah = Dy + DY_BYTES;
+    const int cosub = wave % CO_S, cisub = wave / CO_S;
+    const int ct = blockIdx.y;
+    const int n0 = (ct % p.co_tiles) * CO_T, k0 = (ct / p.co_tiles) * CI_T;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ---- tile-independent item descriptors (as in conv_wgrad16_kernel)
+    unsigned dy_off[DY_ITEMS], ah_off[AH_ITEMS];
+    unsigned long long cls = 0;
+    int dy_lds, ah_lds;
+    {
+        const int pc = tid % DY_PPP, sub = pc / PPS, pin = pc % PPS;
+        const int ch = n0 + pc * EPS;
+        dy_lds = sub * 128 * ROWB + (tid / DY_PPP) * ROWB + pin * 16;
+#pragma unroll
+        for (int it = 0; it < DY_ITEMS; ++it) {
+            const int m = tid / DY_PPP + it * (256 / DY_PPP);
+            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1);
+            dy_off[it] = ch < p.cout ? (unsigned)(wg_rel_pix(0, ty, tx, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ + ch * ESZ) + WG_BIAS : 0xffffffffu;
+        }
+    }
+    float sc[EPS], sh[EPS];
+    {
+        const int pc = tid % AH_PPP, sub = pc / PPS, pin = pc % PPS;
+        const int ch = k0 + pc * EPS;
+        const bool ch_ok = ch < p.cin_pad;
+        ah_lds = sub * HP * ROWB + (tid / AH_PPP) * ROWB + pin * 16;
+#pragma unroll
+        for (int it = 0; it < AH_ITEMS; ++it) {
+            const int idx = tid + it * 256;
+            const int pp = tid / AH_PPP + it * (256 / AH_PPP);
+            const int hy = pp / HW2, hx = pp % HW2;
+            const bool live = idx < AH_PIECES && ch_ok;
+            ah_off[it] = live ? (unsigned)(wg_rel_pix(0, hy - 1, hx - 1, p.H, p.W, p.in_blk) * p.in_cs * ESZ + ch * ESZ) + WG_BIAS : 0xffffffffu;
+            cls |= (unsigned long long)((hx == 0 ? 1u : 0u) | (hx == TW + 1 ? 2u : 0u) | (hy == 0 ? 4u : 0u) | (hy == TH + 1 ? 8u : 0u)) << (4 * it);
+        }
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+        if (p.prologue == PSSR_PRO_BN_RELU && ch_ok) {
+            load4(p.pro_scale + ch, sc); load4(p.pro_scale + ch + 4, sc + 4);
+            load4(p.pro_shift + ch, sh); load4(p.pro_shift + ch + 4, sh + 4);
+        }
+    }
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pcol = li & 3;
+    const int colb = ((g & 1) * 16 + pcol * 4) * 2;
+    const int m00 = (g >> 1) * 8 + q;
+    const char* const dy_rd = Dy + cosub * 128 * ROWB + m00 * ROWB + colb;
+    const char* const ah_rd0 = Ah + cisub * HP * ROWB + wg_halo_pix<GEO>(m00) * ROWB + colb;
+    const char* const ah_rd1 = Ah + cisub * HP * ROWB + wg_halo_pix<GEO>(m00 + 4) * ROWB + colb;
+
+    const char* const dy_base = (const char*)p.dy + (long)p.dy_co * ESZ - WG_BIAS;
+    const char* const in_base = (const char*)p.in + (long)p.in_co * ESZ - WG_BIAS;
+
+    u32x4 dy_reg[DY_ITEMS], ah_reg[AH_ITEMS];
+    unsigned long long ah_bad = 0;
+
+    // ---- this group's tiles: ordinals grp, grp + 2, ... of the workgroup's subset blockIdx.x + o * split
+    const int cnt = (int)blockIdx.x < p.n_tiles ? (p.n_tiles - (int)blockIdx.x + p.split - 1) / p.split : 0;
+    const int n_mine = (cnt - grp + 1) >> 1, n_a = (cnt + 1) >> 1;
+    int tc_x, tc_y, tc_i;                         // coordinates of the next tile to issue (scalar registers)
+    int st_x, st_y, st_i;                         // 2 * split in the same mixed radix
+    {
+        int t0 = (int)blockIdx.x + grp * p.split;
+        tc_x = t0 % p.tiles_x; t0 /= p.tiles_x; tc_y = t0 % p.tiles_y; tc_i = t0 / p.tiles_y;
+        int s2 = 2 * p.split;
+        st_x = s2 % p.tiles_x; s2 /= p.tiles_x; st_y = s2 % p.tiles_y; st_i = s2 / p.tiles_y;
+    }
+
+#define WX_ISSUE()                                                                                                \
+    {                                                                                                             \
+        const int x0_ = tc_x << TWL, y0_ = tc_y << THL, img0_ = tc_i;                                             \
+        const unsigned tb_ = (x0_ == 0 ? 1u : 0u) | (x0_ + TW == p.W ? 2u : 0u) | (y0_ == 0 ? 4u : 0u) | (y0_ + TH == p.H ? 8u : 0u); \
+        ah_bad = cls & (tb_ * 0x1111111111111111ull);                                                             \
+        const __amdgpu_buffer_rsrc_t rdy_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(dy_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rin_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(in_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.in_blk) * p.in_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        _Pragma("unroll") for (int it = 0; it < DY_ITEMS; ++it)                                                   \
+            dy_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy_, (int)dy_off[it], 0, 0)); \
+        _Pragma("unroll") for (int it = 0; it < AH_ITEMS; ++it) {                                                 \
+            const unsigned off_ = ((ah_bad >> (4 * it)) & 0xfu) ? 0xffffffffu : ah_off[it];                       \
+            ah_reg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin_, (int)off_, 0, 0)); \
+        }                                                                                                         \
+        tc_x += st_x;                                                                                             \
+        const int cx_ = tc_x >= p.tiles_x ? 1 : 0;                                                                \
+        tc_x -= cx_ ? p.tiles_x : 0;                                                                              \
+        tc_y += st_y + cx_;                                                                                       \
+        const int cy_ = tc_y >= p.tiles_y ? 1 : 0;                                                                \
+        tc_y -= cy_ ? p.tiles_y : 0;                                                                              \
+        tc_i += st_i + cy_;                                                                                       \
+    }
+#define WX_COMMIT()                                                                                               \
+    {                                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < DY_ITEMS; ++it)                                                   \
+            *(u32x4*)(Dy + dy_lds + it * (256 / DY_PPP) * ROWB) = dy_reg[it];                                     \
+        _Pragma("unroll") for (int it = 0; it < AH_ITEMS; ++it) {                                                 \
+            if ((it + 1) * 256 <= AH_PIECES || tid < AH_PIECES - it * 256) {                                      \
+                u32x4 v = ah_reg[it];                                                                             \
+                if (p.prologue == PSSR_PRO_BN_RELU) {                                                             \
+                    v = X::bn_relu(v, sc, sh);                                                                    \
+                    if ((ah_bad >> (4 * it)) & 0xfu) v = u32x4{0u, 0u, 0u, 0u};                                   \
+                } else if (p.prologue == PSSR_PRO_GELU) {                                                         \
+                    float f[EPS];                                                                                 \
+                    X::unpack(v, f);                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
+                    v = X::pack(f);                                                                               \
+                }                                                                                                 \
+                *(u32x4*)(Ah + ah_lds + it * (256 / AH_PPP) * ROWB) = v;                                          \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+#define WX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+#define WX_MULTIPLY()                                                                                              \
+    {                                                                                                             \
+        u32x4 win[3][3];                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                             \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                      \
+                win[r][kx] = Frag16::load(ah_rd0 + (r * HW2 + kx) * ROWB, ah_rd1 + (r * HW2 + kx) * ROWB);        \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                           \
+            const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);                    \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                      \
+                win[(s + 2) % 3][kx] = Frag16::load(ah_rd0 + ((s + 2) * HW2 + kx) * ROWB, ah_rd1 + ((s + 2) * HW2 + kx) * ROWB); \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) X::mma(acc[t], af, win[(s + t / 3) % 3][t % 3]);        \
+        }                                                                                                         \
+    }
+    // Both groups run the same loop  { commit | barrier | issue next, multiply | barrier };  group B enters it one barrier
+    // later, so A's multiply epoch is B's commit epoch and vice versa (the hardware barrier only counts arrivals).  The
+    // barrier counts are evened out after the loop: A has n_a tiles, B n_a or n_a - 1.
+#ifdef PSSR_WG_STAMPS
+    unsigned long long st_prev = 0;
+    unsigned st_sum[6] = {0, 0, 0, 0, 0, 0};
+#define WX_STAMP(I)                                                                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if ((I) >= 0) st_sum[(I) < 0 ? 0 : (I)] += (unsigned)(t_ - st_prev);                                      \
+        st_prev = t_;                                                                                             \
+    }
+#else
+#define WX_STAMP(I)
+#endif
+    if (n_mine > 0) WX_ISSUE()
+    if (grp == 1) WX_BARRIER();
+    WX_STAMP(-1)
+    for (int j = 0; j < n_mine; ++j) {
+#ifdef PSSR_WG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // segment 0 = exposed load latency
+#endif
+        WX_STAMP(0)
+        WX_COMMIT()
+        WX_STAMP(1)
+        WX_BARRIER();
+        WX_STAMP(2)
+        if (j + 1 < n_mine) WX_ISSUE()
+        WX_STAMP(3)
+        WX_MULTIPLY()
+        WX_STAMP(4)
+        WX_BARRIER();
+        WX_STAMP(5)
+    }
+#ifdef PSSR_WG_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned* q = p.stamps + (((long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) q[i] = st_sum[i];
+        q[6] = n_mine;
+    }
+#endif
+#undef WX_STAMP
+    if (grp == 0) WX_BARRIER();
+    else if (n_mine < n_a) { WX_BARRIER(); WX_BARRIER(); }
+#undef WX_MULTIPLY
+#undef WX_ISSUE
+#undef WX_COMMIT
+
+    // ---- group B hands its accumulators over, 3 taps per round ([slot][thread] float4: conflict-free both ways)
+    float4* const xb = (float4*)smem;
+#ifndef X2_NO_HANDOVER
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (grp == 1) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    xb[(tt * 4 + qq) * 256 + tid] = make_float4(acc[3 * r + tt][4 * qq], acc[3 * r + tt][4 * qq + 1], acc[3 * r + tt][4 * qq + 2], acc[3 * r + tt][4 * qq + 3]);
+        }
+        WX_BARRIER();
+        if (grp == 0) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 v = xb[(tt * 4 + qq) * 256 + tid];
+                    acc[3 * r + tt][4 * qq] += v.x; acc[3 * r + tt][4 * qq + 1] += v.y; acc[3 * r + tt][4 * qq + 2] += v.z; acc[3 * r + tt][4 * qq + 3] += v.w;
+                }
+        }
+        WX_BARRIER();
+    }
+#endif
+#undef WX_BARRIER
+    if (grp != 0) return;
 
     const int kcol = k0 + cisub * 32 + (lane & 31);
     if (kcol < p.cin_pad) {
@@ -669,6 +1007,18 @@ int launch_t(WgradArgs p, hipStream_t stream, int* query) {
         const long span_in = (p.in_blk ? (long)p.H * p.W * NI : (long)(TH + 2) * p.W + (long)(NI - 1) * p.H * p.W) * p.in_cs * 2;
         const int lean = pssr_tunables().wgrad_lean;
         if (lean && full && span_dy < (1L << 30) && span_in < (1L << 30)) {
+            if constexpr (GEO == 0 && TAPS == 9) {
+                if (pssr_tunables().wgrad_x2) {
+                    static bool attrx2_done = false;
+                    if (!attrx2_done) {
+                        (void)hipFuncSetAttribute((const void*)conv_wgrad16x2_kernel<T, CO_T, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS);
+                        attrx2_done = true;
+                    }
+                    hipLaunchKernelGGL((conv_wgrad16x2_kernel<T, CO_T, CI_T>), dim3(split, slabs), dim3(512), 2 * LDS, stream, p);
+                    PSSR_LAUNCH_CHECK();
+                    return PSSR_OK;
+                }
+            }
             static bool attr16_done = false;
             if (!attr16_done) {
                 (void)hipFuncSetAttribute((const void*)conv_wgrad16_kernel<T, CO_T, CI_T, GEO, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -718,6 +1068,11 @@ int launch_shape(const WgradArgs& a, hipStream_t s, int* query) {
 
 static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* query);
 
+#ifdef PSSR_WG_STAMPS
+static unsigned* g_wg_stamp_buf = nullptr;
+extern "C" void pssr_debug_wgrad_stamp_buffer(void* p) { g_wg_stamp_buf = (unsigned*)p; }
+#endif
+
 extern "C" int pssr_conv2d_wgrad(const pssr_wgrad_desc* d, pssr_stream_t stream) { return wgrad_entry(d, stream, nullptr); }
 
 extern "C" int pssr_conv2d_wgrad_parts(const pssr_wgrad_desc* d) {
@@ -747,7 +1102,17 @@ static int wgrad_entry(const pssr_wgrad_desc* d, pssr_stream_t stream, int* quer
     a.in = d->in; a.in_cs = d->in_cstride; a.in_co = d->in_coff; a.in_blk = d->in_blk; a.cin_pad = d->cin_pad;
     a.taps = d->taps; a.prologue = d->prologue; a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
     a.dw = d->dw; a.parts = d->dw_parts; a.part_stride = 0;
+    a.dbg = pssr_tunables().igemm_dbg;
+    a.stamps = nullptr;
+#ifdef PSSR_WG_STAMPS
+    a.stamps = g_wg_stamp_buf;
+#endif
     hipStream_t s = (hipStream_t)stream;
+#ifdef PSSR_WGRAD_DEV       // development builds: instantiate only the kernel being worked on (resource usage / ISA in seconds)
+    hipLaunchKernelGGL((conv_wgrad16x2_kernel<bf16_t, 64, 64>), dim3(1, 1), dim3(512), 0, s, a);
+    return PSSR_OK;
+#else
     return d->dtype == PSSR_BF16 ? launch_shape<bf16_t>(a, s, query)
          : d->dtype == PSSR_F16 ? launch_shape<f16_t>(a, s, query) : launch_shape<float>(a, s, query);
+#endif
 }

@@ -32,6 +32,8 @@ constexpr int HS = TS + 2;             // halo tile edge
 constexpr int HPIX = HS * HS;          // 324
 constexpr int HGROUPS = (HPIX + 15) / 16;   // 21 groups of 16 halo pixels
 
+static unsigned* g_head_stamps = nullptr;      // diagnostic build (-DPSSR_WG_STAMPS) only
+
 struct HeadArgs {
     const void* P; int p_cs, p_co, blk;            // activations (blocked NHWC, bf16 or fp16), cin channels
     void* dP; int dp_cs, dp_co;                     // dgrad output (same layout)
@@ -306,16 +308,37 @@ __device__ __forceinline__ u32x4 tr_frag(const char* a0, const char* a1) {      
     return r;
 }
 
-template <typename H, int NT, bool BS>     // NT = cin/16; cout*9 <= 27; BS: keep the bias sums (NT = 2, 4 or 8)
-__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs p, int n_tiles, float* bsum) {
+template <typename H, int NT, bool BS, bool FULL>     // NT = cin/16; cout*9 <= 27; BS: keep the bias sums (NT = 2, 4 or 8); FULL: H, W multiples of 16
+__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void head_bwd_kernel(const HeadArgs p, int n_tiles, float* bsum, unsigned* stamps) {
+#ifdef PSSR_WG_STAMPS
+    unsigned long long st_prev = 0;
+    unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned st_n = 0;
+#define HB_STAMP(I)                                                                                               \
+    {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if ((I) >= 0) st_sum[(I) < 0 ? 0 : (I)] += (unsigned)(t_ - st_prev);                                      \
+        st_prev = t_;                                                                                             \
+    }
+#else
+#define HB_STAMP(I)
+#endif
     typedef typename HV<H>::v8 v8;
+    typedef __attribute__((ext_vector_type(4))) H v4;
     constexpr int C = NT * 16, CI_S = NT / 2, PPP = C / 8;          // channels, 32-channel sub-tiles, 16-byte pieces per pixel
-    constexpr int G_BYTES = ((3 * HPIX * 4 + 15) / 16) * 16;
+    constexpr int OROW = C * 2 + 16;                                // dP row: 16 bytes of padding spread the 8-byte MFMA stores over the banks
+    constexpr int G_BYTES = ((3 * HPIX * 4 + 15) / 16) * 16 + 16;    // + one slot that stays zero: the target of unused (co, tap) operand slots
+    constexpr int GZ = 3 * HPIX;
+    constexpr int GI = (3 * HPIX + 255) / 256;                      // gradient-tile elements per thread (cout <= 3)
+    constexpr int UNR = NT <= 4 ? 2 : 1;                            // tile rows in flight per wave in the two MFMA phases (register budget: 2 workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* G = (float*)smem;                                        // [cout][HS][HS] incoming gradient tile (+halo), scaled
     char* Pt = smem + G_BYTES;                                      // [CI_S][256 px][64 B] activation tile
-    H* O = (H*)(Pt + 256 * C * 2);                                  // [256 px][C] dP before the mask
-    float* Bs = (float*)((char*)O + 256 * C * 2);                   // [16 sub-pixels][C] bias sums of this workgroup
+    char* O = Pt + 256 * C * 2;                                     // [256 px][OROW] dP before the mask
+    float* Bs = (float*)(O + 256 * OROW);                           // [16 sub-pixels][C] bias sums of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bshift = p.blk, bmask = (1 << p.blk) - 1;
 
@@ -335,7 +358,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs p, int n_t
     const int tg = lane >> 4, tq = (lane & 15) >> 2, tpc = lane & 3;
     const int tr_off = ((tg >> 1) * 8 + tq) * 64 + ((tg & 1) * 16 + tpc * 4) * 2;
     for (int i = tid; i < 16 * C; i += 256) Bs[i] = 0.f;
-    // dgrad A operand: k = (co, tap) slots 8 * (lane >> 4) + j of this lane, as offsets into G for tile pixel (0, 0)
+    if (tid < 4) G[GZ + tid] = 0.f;
+    // dgrad: k = (co, tap) slots 8 * (lane >> 4) + j of this lane, as offsets into G for tile pixel (0, 0)
     int doff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -353,67 +377,115 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs p, int n_t
 #pragma unroll
         for (int j = 0; j < 8; ++j) bacc[k][j] = 0.f;
 
+    // ---- tile-independent piece descriptors.  Full tiles: the offset of a piece from the tile origin does not depend on the
+    // tile (origins are multiples of 16 >= the blocked layout's 2^blk), so a tile costs one scalar origin and PPP adds.
+    int rel_p[PPP], rel_d[PPP];       // element offsets of piece u from the origin pixel, activation / gradient tensor
+#pragma unroll
+    for (int u = 0; u < PPP; ++u) {
+        const int i = tid + u * 256;
+        const int pix = i / PPP, pc = i % PPP;
+        const int dy = pix / TS, dx = pix % TS;
+        const int rp = (((dy >> bshift) * (p.W >> bshift) + (dx >> bshift)) << (2 * bshift)) + ((dy & bmask) << bshift) + (dx & bmask);
+        rel_p[u] = rp * p.p_cs + pc * 8;
+        rel_d[u] = rp * p.dp_cs + pc * 8;
+    }
+    // gradient-tile elements of this thread: halo position -> offset from the tile's (-1, -1) corner in the NCHW plane
+    int g_rel[GI], g_hy[GI], g_hx[GI];
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+        const int i = tid + u * 256;
+        const int co = i / HPIX, hp = i % HPIX;
+        g_hy[u] = hp / HS - 1; g_hx[u] = hp % HS - 1;
+        g_rel[u] = i < p.cout * HPIX ? co * p.H * p.W + g_hy[u] * p.W + g_hx[u] : INT_MIN;      // (plane offset fits: cout <= 3, one image)
+    }
+
     u32x4 pre[PPP];
-    long qv[PPP];
+    float gpre[GI];
+    unsigned okm = 0, okm_cur = 0;    // partial tiles: bit u = piece u lies inside the image
 #define HB_ISSUE(TILE)                                                                                                  \
     {                                                                                                                   \
         int t_ = (TILE);                                                                                                \
         const int tx0_ = (t_ % p.tiles_x) * TS; t_ /= p.tiles_x;                                                        \
         const int ty0_ = (t_ % p.tiles_y) * TS;                                                                         \
         const int img_ = t_ / p.tiles_y;                                                                                \
+        const long org_ = pix_index(img_, ty0_, tx0_, p.H, p.W, p.blk);                                                 \
+        const H* pb_ = (const H*)p.P + org_ * p.p_cs + p.p_co;                                                          \
+        okm = 0;                                                                                                        \
         _Pragma("unroll") for (int u = 0; u < PPP; ++u) {                                                               \
-            const int i = tid + u * 256;                                                                                \
-            const int pix = i / PPP, pc = i % PPP;                                                                      \
-            const int gy = ty0_ + pix / TS, gx = tx0_ + pix % TS;                                                       \
-            const bool ok = gy < p.H && gx < p.W;                                                                       \
-            qv[u] = ok ? pix_index(img_, gy, gx, p.H, p.W, p.blk) : -1;                                                 \
-            pre[u] = *(const u32x4*)((const H*)p.P + (ok ? qv[u] : pix_index(img_, ty0_, tx0_, p.H, p.W, p.blk)) * p.p_cs + p.p_co + pc * 8); \
+            bool ok = true;                                                                                             \
+            if (!FULL) {                                                                                                \
+                const int pix = (tid + u * 256) / PPP;                                                                  \
+                ok = ty0_ + pix / TS < p.H && tx0_ + pix % TS < p.W;                                                    \
+            }                                                                                                           \
+            okm |= (ok ? 1u : 0u) << u;                                                                                 \
+            pre[u] = *(const u32x4*)(pb_ + (ok ? rel_p[u] : 0));                                                        \
+        }                                                                                                               \
+        const float* gb_ = p.g + (long)img_ * p.cout * p.H * p.W + (long)ty0_ * p.W + tx0_;                             \
+        _Pragma("unroll") for (int u = 0; u < GI; ++u) {                                                                \
+            const int gy = ty0_ + g_hy[u], gx = tx0_ + g_hx[u];                                                         \
+            const bool ok = g_rel[u] != INT_MIN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;                               \
+            gpre[u] = ok ? gb_[g_rel[u]] : 0.f;                                                             \
         }                                                                                                               \
     }
     int tile = blockIdx.x;
     if (tile < n_tiles) HB_ISSUE(tile)
+    HB_STAMP(-1)
     for (; tile < n_tiles; tile += gridDim.x) {
+#ifdef PSSR_WG_STAMPS
+        ++st_n;
+#endif
         int t = tile;
         const int tx0 = (t % p.tiles_x) * TS; t /= p.tiles_x;
         const int ty0 = (t % p.tiles_y) * TS;
         const int img = t / p.tiles_y;
-        // ---- stage: activation pieces (prefetched) and the gradient tile
-        long qcur[PPP];
+        H* const db = (H*)p.dP + pix_index(img, ty0, tx0, p.H, p.W, p.blk) * p.dp_cs + p.dp_co;
+        // ---- stage: activation pieces and gradient tile (both prefetched one tile ahead)
+        okm_cur = okm;
 #pragma unroll
         for (int u = 0; u < PPP; ++u) {
             const int i = tid + u * 256;
             const int pix = i / PPP, pc = i % PPP;
-            qcur[u] = qv[u];
             u32x4 v = pre[u];
-            if (qv[u] < 0) v = u32x4{0u, 0u, 0u, 0u};
+            if (!FULL && !((okm >> u) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
             *(u32x4*)(Pt + (pc / 4) * (256 * 64) + pix * 64 + (pc % 4) * 16) = v;
         }
-        for (int i = tid; i < p.cout * HPIX; i += 256) {
-            const int co = i / HPIX, hp = i % HPIX;
-            const int gy = ty0 + hp / HS - 1, gx = tx0 + hp % HS - 1;
-            G[i] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? p.g[(((long)img * p.cout + co) * p.H + gy) * p.W + gx] * p.g_scale : 0.f;
+#pragma unroll
+        for (int u = 0; u < GI; ++u) {
+            const int i = tid + u * 256;
+            if (i < p.cout * HPIX) G[i] = gpre[u] * p.g_scale;
         }
+        HB_STAMP(0)
         __syncthreads();
+        HB_STAMP(1)
         if (tile + (int)gridDim.x < n_tiles) HB_ISSUE(tile + gridDim.x)
+        HB_STAMP(2)
 
-        // ---- dP = g (*) W, 16 pixels (one tile row) per MFMA chain
-        for (int g = wave; g < 16; g += 4) {
+        // ---- dP^T = W^T (*) g: one tile row of 16 pixels per MFMA chain; a lane ends up with 4 consecutive channels of one
+        // pixel, stored as one 8-byte piece (the row-major product would need 16 two-byte stores per row instead of 4)
+#pragma unroll (UNR)
+        for (int gi = 0; gi < 4; ++gi) {
+            const int g = wave + 4 * gi;
             const int px = lane & 15, py = g;
             v8 a;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (H)(doff[j] >= 0 ? G[doff[j] + py * HS + px] : 0.f);
+            for (int j = 0; j < 8; ++j) a[j] = (H)G[doff[j] >= 0 ? doff[j] + py * HS + px : GZ];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                f32x4_t acc = HV<H>::mma(a, bw[nt], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                const f32x4_t acc = HV<H>::mma(bw[nt], a, f32x4_t{0.f, 0.f, 0.f, 0.f});
+                v4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) O[(g * 16 + (lane >> 4) * 4 + r) * C + nt * 16 + (lane & 15)] = (H)acc[r];
+                for (int r = 0; r < 4; ++r) o[r] = (H)acc[r];
+                *(v4*)(O + (g * 16 + px) * OROW + (nt * 16 + (lane >> 4) * 4) * 2) = o;
             }
         }
+        HB_STAMP(3)
         // ---- dW[(co,tap)][ci] += sum over the tile's pixels of g[q - off(tap)] * P[q]: k-steps of 16 pixels = tile rows
-        for (int ks = wave; ks < 16; ks += 4) {
+#pragma unroll (UNR)
+        for (int ki = 0; ki < 4; ++ki) {
+            const int ks = wave + 4 * ki;
             float gv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gv[j] = gbase >= 0 ? G[gbase + ks * HS + j] : 0.f;
+            for (int j = 0; j < 8; ++j) gv[j] = G[gbase >= 0 ? gbase + ks * HS + j : GZ];
             u32x4 af;
             {
                 v8 a8;
@@ -427,25 +499,43 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs p, int n_t
                 accw[s_] = HV32<H>::mma(af, tr_frag(b0, b0 + 4 * 64), accw[s_]);
             }
         }
+        HB_STAMP(4)
         __syncthreads();
-        // ---- masked write-out (16-byte pieces, whole pixel rows per wave) + bias sums per (sub-pixel, channel)
+        HB_STAMP(5)
+        // ---- masked write-out (16-byte pieces, whole pixel rows per wave) + bias sums per (sub-pixel, channel).  The ReLU mask
+        // is a packed 16-bit test: a bf16 / fp16 value is > 0 exactly when its bit pattern is > 0 as a signed 16-bit integer
 #pragma unroll
         for (int u = 0; u < PPP; ++u) {
-            if (qcur[u] < 0) continue;
+            if (!FULL && !((okm_cur >> u) & 1u)) continue;
             const int i = tid + u * 256;
             const int pix = i / PPP, pc = i % PPP;
-            v8 v = *(const v8*)(O + pix * C + pc * 8);
-            const v8 actv = *(const v8*)(Pt + (pc / 4) * (256 * 64) + pix * 64 + (pc % 4) * 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (!((float)actv[j] > 0.f)) v[j] = (H)0.f;
-            *(v8*)((H*)p.dP + qcur[u] * p.dp_cs + p.dp_co + pc * 8) = v;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+            const u16x8 raw = *(const u16x8*)(O + pix * OROW + pc * 16);
+            const s16x8 actv = *(const s16x8*)(Pt + (pc / 4) * (256 * 64) + pix * 64 + (pc % 4) * 16);
+            const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1}, ones = {0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff};
+            const u16x8 pos = __builtin_elementwise_min(__builtin_bit_cast(u16x8, __builtin_elementwise_max(actv, zero)), one);
+            const u16x8 mv = raw & (pos * ones);
+            const v8 v = __builtin_bit_cast(v8, mv);
+            *(v8*)(db + rel_d[u]) = v;
             if (BS) {       // this thread's piece u always lies on sub-pixel row set u % NS and one sub-pixel column
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bacc[u % NS][j] += (float)v[j];
             }
         }
+        HB_STAMP(6)
         __syncthreads();
+        HB_STAMP(7)
     }
+#ifdef PSSR_WG_STAMPS
+    if (stamps && lane == 0) {
+        unsigned* q = stamps + ((long)blockIdx.x * 4 + wave) * 12;
+        for (int i = 0; i < 8; ++i) q[i] = st_sum[i];
+        q[8] = st_n;
+    }
+#endif
+#undef HB_STAMP
 #undef HB_ISSUE
     // ---- dW: one f32 atomic per weight and wave
     const int kcol = lane & 31;
@@ -555,6 +645,10 @@ int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, in
     return PSSR_OK;
 }
 
+#ifdef PSSR_WG_STAMPS
+void pssr_debug_head_stamp_buffer(void* p) { g_head_stamps = (unsigned*)p; }
+#endif
+
 int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
                        int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin, int cout, int dtype,
                        pssr_stream_t s) {
@@ -568,22 +662,25 @@ int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, 
     a.N = n; a.H = h; a.W = w; a.cin = cin; a.cout = cout; a.tiles_x = cdiv(w, TS); a.tiles_y = cdiv(h, TS);
     const long tiles = (long)a.tiles_x * a.tiles_y * n;
     PSSR_CHECK(tiles < (1L << 31), PSSR_ERR_ARG, "head_conv_bwd: grid");
-    const int lds = ((3 * HPIX * 4 + 15) / 16) * 16 + 2 * 256 * cin * 2 + 16 * cin * 4;
+    const int lds = ((3 * HPIX * 4 + 15) / 16) * 16 + 16 + 256 * cin * 2 + 256 * (cin * 2 + 16) + 16 * cin * 4;
+    const bool full = h % TS == 0 && w % TS == 0;
     const int grid = tiles < 512 ? (int)tiles : 512;
-#define HB(NT_, BS_)                                                                                                       \
+#define HB2(NT_, BS_, FULL_)                                                                                                \
     do {                                                                                                                \
         if (dtype == PSSR_BF16) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<bf16_t, NT_, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((head_bwd_kernel<bf16_t, NT_, BS_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum); \
+            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<bf16_t, NT_, BS_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((head_bwd_kernel<bf16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps); \
         } else {                                                                                                        \
-            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<f16_t, NT_, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((head_bwd_kernel<f16_t, NT_, BS_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum); \
+            (void)hipFuncSetAttribute((const void*)head_bwd_kernel<f16_t, NT_, BS_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((head_bwd_kernel<f16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps); \
         }                                                                                                               \
     } while (0)
+#define HB(NT_, BS_) do { if (full) HB2(NT_, BS_, true); else HB2(NT_, BS_, false); } while (0)
     PSSR_CHECK(!bias_sum || cin == 32 || cin == 64 || cin == 128, PSSR_ERR_ARG, "head_conv_bwd: bias sums need cin = 32, 64 or 128");
     if (bias_sum) { switch (cin / 16) { case 2: HB(2, true); break; case 4: HB(4, true); break; default: HB(8, true); break; } }
     else { switch (cin / 16) { case 2: HB(2, false); break; case 4: HB(4, false); break; case 6: HB(6, false); break; default: HB(8, false); break; } }
 #undef HB
+#undef HB2
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

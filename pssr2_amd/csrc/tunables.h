@@ -13,6 +13,7 @@ struct PssrTunables {
     int igemm_ksplit;       // workgroups a split-K launch of the 128-pixel loop aims for
     int conv_epi8;          // straight-line 8-channel epilogue
     int wgrad_lean;         // lean-loader weight-gradient kernel
+    int wgrad_x2;           // 3x3 weight gradients of 16x8-pixel tiles: 512-thread workgroups of two phase-shifted wave groups (0 off)
     int wgrad_blocks;       // partial slabs of a 3x3 weight gradient
     int wgrad_blocks_1x1;   // ... of a 1x1 weight gradient
     int dwconv_tile;        // LDS-tiled depthwise 7x7
