@@ -1,5 +1,5 @@
 import time, torch, sys, os
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 from oracle import loss_ref, model_ref
 sd = model_ref.make_state_dict(seed=1, randomize_bn=False)
 params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}

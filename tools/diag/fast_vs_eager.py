@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import sys, os; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2])); sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2] / 'tests'))
 import io, contextlib
 import numpy as np, torch
 import test_gpu_fastpath as T

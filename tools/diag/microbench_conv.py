@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 from pssr2_amd import ops, _lib as L
 dt = torch.bfloat16; code = L.BF16

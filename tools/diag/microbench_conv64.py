@@ -1,5 +1,5 @@
 """3x3 conv 1024 -> 64 @128^2 x 32 (the data gradient of the 64 -> 1024 pre-shuffle conv): PSSR_IGEMM_V3_64=0/1"""
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 from pssr2_amd import ops, _lib as L
 dt = torch.bfloat16; code = L.BF16

@@ -1,5 +1,5 @@
 """head (3x3 conv 64 -> 1 @512^2, batch 32) kernels: forward and the fused backward"""
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 from pssr2_amd import ops, _lib as L
 N, H, W, C, blk = 32, 512, 512, 64, 2

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 from pssr2_amd.util import SSIMLoss
 x = torch.rand(32, 1, 512, 512, device="cuda", requires_grad=True); y = torch.rand(32, 1, 512, 512, device="cuda")

@@ -1,11 +1,11 @@
 """Diagnostic build only (make -C pssr2_amd/csrc stamps): where head_bwd_kernel (3x3 conv 64 -> 1 @512^2 backward) spends a tile.
 segments: 0 stage (wait for the prefetch, activation + gradient tile to LDS), 1 barrier, 2 issue next tile, 3 dP (dgrad MFMAs + LDS out),
 4 dW, 5 barrier, 6 masked write-out, 7 barrier"""
-import sys, time; sys.path.insert(0, '/root/repo')
+import sys, time; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 import pssr2_amd._lib as L
 from pathlib import Path
-L._LIB_PATH = Path('/root/repo/pssr2_amd/libpssr_mi355_stamps.so')
+L._LIB_PATH = Path(__file__).resolve().parents[2] / 'pssr2_amd' / 'libpssr_mi355_stamps.so'
 from pssr2_amd import ops
 N, H, W, C, blk = 32, 512, 512, 64, 2
 lib = L.lib()

@@ -1,10 +1,10 @@
 """Diagnostic build only (libpssr_mi355_stamps.so, -DPSSR_V3_STAMPS): where a v3 stage spends its cycles.
 segments: 0 = stage start -> DMA / image loads issued; 1 = multiply (asm block); 2 = image commit; 3 = wait + barrier; 4 = prologue"""
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 import pssr2_amd._lib as L
 from pathlib import Path
-L._LIB_PATH = Path('/root/repo/pssr2_amd/libpssr_mi355_stamps.so')
+L._LIB_PATH = Path(__file__).resolve().parents[2] / 'pssr2_amd' / 'libpssr_mi355_stamps.so'
 from pssr2_amd import ops
 dt = torch.bfloat16; code = L.BF16
 N = 32

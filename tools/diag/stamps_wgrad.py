@@ -1,10 +1,10 @@
 """Diagnostic build only (libpssr_mi355_stamps.so, make -C pssr2_amd/csrc stamps): where a weight-gradient pixel tile spends its cycles.
 segments: 0 = exposed load wait, 1 = commit (prologue + LDS writes), 2 = barrier, 3 = issue next tile's loads, 4 = multiply, 5 = end barrier"""
-import sys; sys.path.insert(0, '/root/repo')
+import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
 import pssr2_amd._lib as L
 from pathlib import Path
-L._LIB_PATH = Path('/root/repo/pssr2_amd/libpssr_mi355_stamps.so')
+L._LIB_PATH = Path(__file__).resolve().parents[2] / 'pssr2_amd' / 'libpssr_mi355_stamps.so'
 from pssr2_amd import ops
 dt = torch.bfloat16; code = L.BF16
 N = 32
