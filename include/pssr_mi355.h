@@ -275,6 +275,25 @@ int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w
                         int k, float c1, float c2, const float* wts, int use_ssim, const float* dcoarse,
                         int hc, int wc, const float* l1_coef, float* dx, pssr_stream_t stream);
 
+/* The same pair with the per-position derivatives kept between the passes (training; 11-tap window only): the forward also stores
+ * `adj` = [planes][3][h][w] f32 -- d(cs or ssim map)/d(mu_x, E[x^2], E[xy]) at every valid position, per unit of upstream weight
+ * (use_ssim: the last MS-SSIM level / plain SSIM) -- and the backward filters those three maps instead of recomputing the five
+ * forward maps on a 20-pixel-wider halo first (78 k instead of 295 k multiply-adds per 32 x 32 tile).  Same values as the pair above
+ * up to the rounding of one reassociated product. */
+int pssr_ssim_level_fwd_adj(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1,
+                            float c2, int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj,
+                            pssr_stream_t stream);
+/* `sums` / `l1_sum` of pssr_ssim_level_fwd_adj are `stripes` copies `stripe_stride` doubles apart (a workgroup adds to one of them:
+ * a 512^2 x 32 level ends with 8192 workgroups); pssr_msssim_weights_striped folds them in a fixed order into `folded`
+ * ([levels * planes * 2 + 1] doubles) before doing what pssr_msssim_weights does. */
+int pssr_msssim_weights_striped(const double* sums, int stripes, int64_t stripe_stride, double* folded, int levels, int planes,
+                                const double* nvalid, const float* level_weights, int ms, float mix, const double* l1_sum,
+                                double l1_numel, const float* grad_out, float* loss_out, float* wts, float* l1_coef,
+                                pssr_stream_t stream);
+int pssr_ssim_level_bwd_adj(const float* x, const float* y, const float* adj, int planes, int h, int w, const float* win_host,
+                            int k, const float* wts, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx,
+                            pssr_stream_t stream);
+
 /* torch.optim.AdamW step (decoupled weight decay) over flat f32 buffers; `step` is 1-based. */
 int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale,

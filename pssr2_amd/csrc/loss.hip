@@ -123,9 +123,25 @@ __global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__
 }
 
 // loss and upstream weights.  sums: [levels][planes][2] (cs sum, ssim sum); nvalid[l] = valid positions per plane.
-__global__ void weights_kernel(const double* sums, int levels, int planes, const double* nvalid, const float* lvl_w, int ms,
-                               float mix, const double* l1_sum, double l1_numel, const float* grad_out,
-                               float* loss_out, float* wts /*[levels][planes]*/, float* l1_coef) {
+__global__ void weights_kernel(const double* sums_in, int levels, int planes, const double* nvalid, const float* lvl_w, int ms,
+                               float mix, const double* l1_sum_in, double l1_numel, const float* grad_out,
+                               float* loss_out, float* wts /*[levels][planes]*/, float* l1_coef, int stripes, long stripe_stride,
+                               double* folded /* [levels * planes * 2 + 1] scratch when stripes > 1 */) {
+    // striped sums (ssim_fwd_adj_k): fold the copies first, in a fixed order
+    const double* sums = sums_in;
+    const double* l1_sum = l1_sum_in;
+    if (stripes > 1) {
+        const int nvals = levels * planes * 2;
+        for (int i = threadIdx.x; i <= nvals; i += 256) {
+            const double* src = i < nvals ? sums_in + i : l1_sum_in;
+            double t = 0.0;
+            if (src) for (int k = 0; k < stripes; ++k) t += src[(long)k * stripe_stride];
+            folded[i] = t;
+        }
+        __syncthreads();
+        sums = folded;
+        if (l1_sum_in) l1_sum = folded + nvals;
+    }
     __shared__ double acc[256];
     const int tid = threadIdx.x;
     const float go = grad_out ? grad_out[0] : 1.f;
@@ -295,10 +311,11 @@ template <int K>
 __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
                                                   Win win, float C1, float C2, double* sums, double* l1_sum) {
     constexpr int halo = K - 1, IN = TS + halo, SEG = 8, NS = TS / SEG;
+    constexpr int HPW = TS + 1;                // row pitch of the h-pass images: the 8 rows a lane group writes fall on different banks
     extern __shared__ float lds[];
     float* xs = lds;
     float* ys = xs + IN * IN;
-    float* hp = ys + IN * IN;                  // [5][IN][TS]
+    float* hp = ys + IN * IN;                  // [5][IN][HPW]
     const int plane = blockIdx.z;
     const int oy0 = blockIdx.y * TS, ox0 = blockIdx.x * TS;
     const int VH = H - halo, VW = W - halo;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
 #pragma unroll
         for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int j = 0; j < SEG; ++j) hp[q * IN * TS + r * TS + c0 + j] = o[q][j];
+            for (int j = 0; j < SEG; ++j) hp[q * IN * HPW + r * HPW + c0 + j] = o[q][j];
     }
     __syncthreads();
     float cs_acc = 0.f, ss_acc = 0.f;
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
 #pragma unroll
         for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int j = 0; j < SEG + K - 1; ++j) v[q][j] = hp[q * IN * TS + (r0 + j) * TS + c];
+            for (int j = 0; j < SEG + K - 1; ++j) v[q][j] = hp[q * IN * HPW + (r0 + j) * HPW + c];
         float m[5][SEG];
         fir_seg<K, SEG, 5>(v, win, m);
 #pragma unroll
@@ -373,8 +390,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
             if (oy0 + r0 + j >= VH || ox0 + c >= VW) continue;
             const float mx = m[0][j], my = m[1][j];
             const float sxx = m[2][j] - mx * mx, syy = m[3][j] - my * my, sxy = m[4][j] - mx * my;
-            const float cs = (2.f * sxy + C2) / (sxx + syy + C2);
-            const float lum = (2.f * mx * my + C1) / (mx * mx + my * my + C1);
+            const float Dcs = sxx + syy + C2;
+            const float cs = (2.f * sxy + C2) / Dcs;
+            const float Dl = mx * mx + my * my + C1;
+            const float lum = (2.f * mx * my + C1) / Dl;
             cs_acc += cs; ss_acc += lum * cs;
         }
     }
@@ -389,6 +408,257 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
         atomicAdd(sums + plane * 2, (double)red[0][0]);
         atomicAdd(sums + plane * 2 + 1, (double)red[1][0]);
         if (l1_sum) atomicAdd(l1_sum, (double)red[2][0]);
+    }
+}
+
+// Training forward (11-tap window): as ssim_fwd_k, plus the adjoint maps for ssim_bwd_adj_k.  The five filtered maps go through ONE
+// horizontal-pass image one after the other (xs / ys + one map: 19.7 KB per workgroup instead of 41.6 KB, so 5-8 workgroups per CU
+// instead of 3: this kernel, too, spent most of its wave cycles in waits), the vertical results stay in registers; the per-plane sums
+// are spread over `stripes` copies (a level-0 launch ended with 256 f64 atomics per address and 8192 on the L1 sum: 59 of 217 us).
+template <int K>
+__global__ __launch_bounds__(256) void ssim_fwd_adj_k(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
+                                                      Win win, float C1, float C2, double* sums, double* l1_sum, int stripes, long stripe_stride,
+                                                      float* __restrict__ adj, int use_ssim) {
+    constexpr int halo = K - 1, IN = TS + halo, SEG = 8, NS = TS / SEG;
+    constexpr int HPW = TS + 1;
+    extern __shared__ float lds[];
+    float* xs = lds;
+    float* ys = xs + IN * IN;
+    float* hp = ys + IN * IN;                  // [IN][HPW]: one map at a time
+    const int plane = blockIdx.z;
+    const int oy0 = blockIdx.y * TS, ox0 = blockIdx.x * TS;
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const int tid = threadIdx.x;
+    float l1 = 0.f;
+    for (int i = tid; i < IN * IN; i += 256) {
+        const int r = i / IN, c = i % IN;
+        const int gy = oy0 + r, gx = ox0 + c;
+        float xv = 0.f, yv = 0.f;
+        if (gy < H && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        xs[i] = xv; ys[i] = yv;
+    }
+    __syncthreads();
+    if (l1_sum) {
+        constexpr int r5 = K / 2;
+        float wsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) wsum += win.g[t];
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int r = i / TS, c = i % TS;
+            const int gy = oy0 + r, gx = ox0 + c;
+            if (gy < H && gx < W) {
+                float sy = wsum, sx = wsum;
+                if (gy < r5 || gy >= H - r5) {
+                    sy = 0.f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { const int yy = gy + t - r5; if (yy >= 0 && yy < H) sy += win.g[t]; }
+                }
+                if (gx < r5 || gx >= W - r5) {
+                    sx = 0.f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { const int xx = gx + t - r5; if (xx >= 0 && xx < W) sx += win.g[t]; }
+                }
+                l1 += fabsf(xs[r * IN + c] - ys[r * IN + c]) * sy * sx;
+            }
+        }
+    }
+    // vertical item of this thread (the first TS * NS threads): column vc, rows vr0 .. vr0 + SEG - 1; its five filtered values
+    const bool vitem = tid < TS * NS;
+    const int vc = tid % TS, vr0 = (tid / TS) * SEG;
+    float m[5][SEG];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        // horizontal pass of map q (x, y, x^2, y^2, xy): item = (row, segment of SEG output columns)
+        for (int it = tid; it < IN * NS; it += 256) {
+            const int r = it / NS, c0 = (it % NS) * SEG;
+            float v[1][SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) {
+                const float a = (q == 1 || q == 3) ? 0.f : xs[r * IN + c0 + j];
+                const float b = (q == 0 || q == 2) ? 0.f : ys[r * IN + c0 + j];
+                v[0][j] = q == 0 ? a : q == 1 ? b : q == 2 ? a * a : q == 3 ? b * b : a * b;
+            }
+            float o[1][SEG];
+            fir_seg<K, SEG, 1>(v, win, o);
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) hp[r * HPW + c0 + j] = o[0][j];
+        }
+        __syncthreads();
+        if (vitem) {
+            float v[1][SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[0][j] = hp[(vr0 + j) * HPW + vc];
+            float o[1][SEG];
+            fir_seg<K, SEG, 1>(v, win, o);
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) m[q][j] = o[0][j];
+        }
+        if (q < 4) __syncthreads();
+    }
+    float cs_acc = 0.f, ss_acc = 0.f;
+    if (vitem) {
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            if (oy0 + vr0 + j >= VH || ox0 + vc >= VW) continue;
+            const float mx = m[0][j], my = m[1][j];
+            const float sxx = m[2][j] - mx * mx, syy = m[3][j] - my * my, sxy = m[4][j] - mx * my;
+            const float Dcs = sxx + syy + C2;
+            const float cs = (2.f * sxy + C2) / Dcs;
+            const float Dl = mx * mx + my * my + C1;
+            const float lum = (2.f * mx * my + C1) / Dl;
+            cs_acc += cs; ss_acc += lum * cs;
+            // the map's derivatives wrt (mu_x, E[x^2], E[xy]) at this position, per unit of upstream weight: what the backward
+            // pass used to recompute from x and y on a (TS + 20) x (TS + 10) halo (5 filtered maps) before its own 3 filters
+            const float dcs_dmx = 2.f * (cs * mx - my) / Dcs, dcs_dexx = -cs / Dcs, dcs_dexy = 2.f / Dcs;
+            float a = dcs_dmx, b = dcs_dexx, cc = dcs_dexy;
+            if (use_ssim) {
+                const float dl_dmx = 2.f * (my - lum * mx) / Dl;
+                a = lum * dcs_dmx + cs * dl_dmx; b = lum * dcs_dexx; cc = lum * dcs_dexy;
+            }
+            float* ap = adj + ((long)plane * 3 * H + (oy0 + vr0 + j)) * W + ox0 + vc;
+            ap[0] = a; ap[(long)H * W] = b; ap[2L * H * W] = cc;
+        }
+    }
+    __shared__ float red[3][256];
+    red[0][tid] = cs_acc; red[1][tid] = ss_acc; red[2][tid] = l1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long so = (long)((blockIdx.x + blockIdx.y * 5) % stripes) * stripe_stride;
+        atomicAdd(sums + so + plane * 2, (double)red[0][0]);
+        atomicAdd(sums + so + plane * 2 + 1, (double)red[1][0]);
+        if (l1_sum) atomicAdd(l1_sum + so, (double)red[2][0]);
+    }
+}
+
+// Backward from the adjoint maps the forward pass stored ([plane][3][H][W], valid positions only): scale by the plane's upstream
+// weight, apply the transposed separable filter, add the chain-rule factors (1, 2x, y), the avg-pool gradient of the coarser level
+// and the L1 term.  3 filtered maps on a (TS + 10)^2 halo instead of 5 + 3: 78 k instead of 295 k FMAs per 32 x 32 tile.
+// The three maps go through ONE pair of LDS images one after the other (13.8 KB per workgroup: 8 workgroups per CU instead of 3 --
+// the counters of the all-at-once version: 71 % of the wave cycles in waits, 15 % issuing vector instructions), the next map's tile
+// is requested before the current one is filtered, and the per-tile index arithmetic is done once.
+template <int K>
+__global__ __launch_bounds__(256) void ssim_bwd_adj_k(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ ADJ,
+                                                      int H, int W, Win win, const float* __restrict__ wts,
+                                                      const float* __restrict__ dcoarse, int HC, int WC, const float* l1_coef_p,
+                                                      float* __restrict__ dX) {
+    constexpr int halo = K - 1, AD = TS + halo;
+    constexpr int SEG = 8, NS = TS / SEG;
+    constexpr int ADC = AD + 1;                            // row pitch of the adjoint tile (odd: the rows of a lane group on different banks)
+    constexpr int THR = AD + SEG, THW = TS + 1;
+    constexpr int NL = (AD * AD + 255) / 256;              // tile elements per thread
+    extern __shared__ float lds[];
+    float* ad = lds;                       // [AD][ADC]
+    float* th = lds + AD * ADC;            // [THR][THW]
+    const int plane = blockIdx.z;
+    const int qy0 = blockIdx.y * TS, qx0 = blockIdx.x * TS;
+    const int VH = H - halo, VW = W - halo;
+    const float* xp = X + (long)plane * H * W;
+    const float* yp = Y + (long)plane * H * W;
+    const float* ap = ADJ + (long)plane * 3 * H * W;
+    const int tid = threadIdx.x;
+    const float wt = wts[plane];
+    // tile elements of this thread: offset in a map (or -1 outside the valid region) and LDS slot
+    int goff[NL], lslot[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = tid + u * 256;
+        const int r = i / AD, c = i - r * AD;
+        const int py = qy0 - halo + r, px = qx0 - halo + c;
+        lslot[u] = i < AD * AD ? r * ADC + c : -1;
+        goff[u] = (i < AD * AD && py >= 0 && py < VH && px >= 0 && px < VW) ? py * W + px : -1;
+    }
+    float pre[NL];
+#define SB_LOAD(Q)                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < NL; ++u) pre[u] = goff[u] >= 0 ? wt * ap[(long)(Q) * H * W + goff[u]] : 0.f;
+    SB_LOAD(0)
+    // vertical item of this thread (the first TS * NS threads): column c, rows r0 .. r0 + SEG - 1; its x / y values
+    const bool vitem = tid < TS * NS;
+    const int vc = tid % TS, vr0 = (tid / TS) * SEG;
+    float xv[SEG], yv[SEG], gsum[SEG];
+#pragma unroll
+    for (int o = 0; o < SEG; ++o) {
+        const int gy = qy0 + vr0 + o, gx = qx0 + vc;
+        const bool ok = vitem && gy < H && gx < W;
+        xv[o] = ok ? xp[(long)gy * W + gx] : 0.f;
+        yv[o] = ok ? yp[(long)gy * W + gx] : 0.f;
+        gsum[o] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) if (lslot[u] >= 0) ad[lslot[u]] = pre[u];
+        __syncthreads();
+        if (q < 2) { SB_LOAD(q + 1) }
+        // transposed filter, horizontal: th[r][x] = sum_t g[t] * ad[r][x + halo - t]
+        for (int it = tid; it < AD * NS; it += 256) {
+            const int r = it / NS, c0 = (it % NS) * SEG;
+            float v[SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[j] = ad[r * ADC + c0 + j];
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) s_ = fmaf(win.g[t], v[o + halo - t], s_);
+                th[r * THW + c0 + o] = s_;
+            }
+        }
+        __syncthreads();
+        if (vitem) {
+            float v[SEG + K - 1];
+#pragma unroll
+            for (int j = 0; j < SEG + K - 1; ++j) v[j] = th[(vr0 + j) * THW + vc];
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) a = fmaf(win.g[t], v[o + halo - t], a);
+                // g = s0 + 2 x s1 + y s2, summed in that order (as the all-at-once kernel did)
+                if (q == 0) gsum[o] = a;
+                else if (q == 1) gsum[o] = gsum[o] + 2.f * xv[o] * a;
+                else gsum[o] = gsum[o] + yv[o] * a;
+            }
+        }
+    }
+#undef SB_LOAD
+    if (!vitem) return;
+    const float l1c = l1_coef_p ? l1_coef_p[0] : 0.f;
+    constexpr int r5 = K / 2;
+    float wsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < K; ++t) wsum += win.g[t];
+    float* dxp = dX + (long)plane * H * W;
+#pragma unroll
+    for (int o = 0; o < SEG; ++o) {
+        const int gy = qy0 + vr0 + o, gx = qx0 + vc;
+        if (gy >= H || gx >= W) continue;
+        float g = gsum[o];
+        if (dcoarse) {
+            const int cy = (gy + (H & 1)) >> 1, cx = (gx + (W & 1)) >> 1;
+            g += 0.25f * dcoarse[((long)plane * HC + cy) * WC + cx];
+        }
+        if (l1c != 0.f) {
+            float sy = wsum, sx = wsum;
+            if (gy < r5 || gy >= H - r5) {
+                sy = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) { const int yy = gy + t - r5; if (yy >= 0 && yy < H) sy += win.g[t]; }
+            }
+            if (gx < r5 || gx >= W - r5) {
+                sx = 0.f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) { const int xx = gx + t - r5; if (xx >= 0 && xx < W) sx += win.g[t]; }
+            }
+            const float d = xv[o] - yv[o];
+            g += l1c * sy * sx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        dxp[(long)gy * W + gx] = g;
     }
 }
 
@@ -571,7 +841,7 @@ int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w
     PSSR_CHECK(x && y && sums && win_host && planes > 0 && k > 0 && k <= MAXW && (k & 1), PSSR_ERR_ARG, "ssim_level_fwd: bad args");
     PSSR_CHECK(h >= k && w >= k, PSSR_ERR_ARG, "ssim_level_fwd: image %dx%d smaller than window %d", h, w, k);
     const int IN = TS + k - 1;
-    const size_t lds = (size_t)(2 * IN * IN + 5 * IN * TS) * sizeof(float);
+    const size_t lds = (size_t)(2 * IN * IN + 5 * IN * (TS + 1)) * sizeof(float);
     // when the L1 term is requested the tiles must cover the whole image, not only the valid region
     const int eh = l1_sum ? h : h - k + 1, ew = l1_sum ? w : w - k + 1;
     static bool attr = false;
@@ -586,6 +856,31 @@ int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w
     else
         hipLaunchKernelGGL(ssim_fwd_kernel<0>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
                            make_win(win_host, k), c1, c2, sums, l1_sum);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_ssim_level_fwd_adj(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1, float c2,
+                            int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj, pssr_stream_t s) {
+    PSSR_CHECK(x && y && sums && win_host && planes > 0 && adj && k == 11, PSSR_ERR_ARG,
+               "ssim_level_fwd_adj: needs the adjoint buffer and the 11-tap window (k=%d)", k);
+    PSSR_CHECK(h >= k && w >= k && stripes >= 1 && (stripes == 1 || stripe_stride > 0), PSSR_ERR_ARG, "ssim_level_fwd_adj: bad size / stripes");
+    const int IN = TS + k - 1;
+    const size_t lds = (size_t)(2 * IN * IN + IN * (TS + 1)) * sizeof(float);
+    const int eh = l1_sum ? h : h - k + 1, ew = l1_sum ? w : w - k + 1;
+    hipLaunchKernelGGL(ssim_fwd_adj_k<11>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
+                       make_win(win_host, k), c1, c2, sums, l1_sum, stripes, (long)stripe_stride, adj, use_ssim);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_ssim_level_bwd_adj(const float* x, const float* y, const float* adj, int planes, int h, int w, const float* win_host, int k,
+                            const float* wts, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx, pssr_stream_t s) {
+    PSSR_CHECK(x && y && adj && wts && dx && win_host && planes > 0 && k == 11, PSSR_ERR_ARG, "ssim_level_bwd_adj: bad args (k=%d)", k);
+    constexpr int AD = TS + 10;
+    const size_t lds = (size_t)(AD * (AD + 1) + (AD + 8) * (TS + 1)) * sizeof(float);
+    hipLaunchKernelGGL(ssim_bwd_adj_k<11>, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, adj, h, w,
+                       make_win(win_host, k), wts, dcoarse, hc, wc, l1_coef, dx);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -605,7 +900,18 @@ int pssr_msssim_weights(const double* sums, int levels, int planes, const double
                         float* l1_coef, pssr_stream_t s) {
     PSSR_CHECK(sums && nvalid && loss_out && wts && l1_coef && levels > 0 && levels <= 8 && planes > 0, PSSR_ERR_ARG, "msssim_weights: bad args");
     hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, sums, levels, planes, nvalid, level_weights, ms, mix,
-                       l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef);
+                       l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef, 1, 0L, (double*)nullptr);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_msssim_weights_striped(const double* sums, int stripes, int64_t stripe_stride, double* folded, int levels, int planes,
+                                const double* nvalid, const float* level_weights, int ms, float mix, const double* l1_sum,
+                                double l1_numel, const float* grad_out, float* loss_out, float* wts, float* l1_coef, pssr_stream_t s) {
+    PSSR_CHECK(sums && folded && stripes >= 1 && stripe_stride > 0 && nvalid && loss_out && wts && l1_coef && levels > 0 && levels <= 8 && planes > 0,
+               PSSR_ERR_ARG, "msssim_weights_striped: bad args");
+    hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, sums, levels, planes, nvalid, level_weights, ms, mix,
+                       l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef, stripes, (long)stripe_stride, folded);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

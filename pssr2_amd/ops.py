@@ -235,6 +235,26 @@ def ssim_level_fwd(x, y, planes, h, w, win, c1, c2, sums, l1_sum=None):
                                         L.ptr(l1_sum), L.stream_ptr()), "pssr_ssim_level_fwd")
 
 
+def ssim_level_fwd_adj(x, y, planes, h, w, win, c1, c2, use_ssim, sums, l1_sum, stripes, stripe_stride, adj):
+    k = len(win); arr = (C.c_float * k)(*win)
+    L.check(L.lib().pssr_ssim_level_fwd_adj(L.ptr(x), L.ptr(y), planes, h, w, arr, k, C.c_float(c1), C.c_float(c2), int(use_ssim), L.ptr(sums),
+                                            L.ptr(l1_sum), stripes, C.c_int64(stripe_stride), L.ptr(adj), L.stream_ptr()), "pssr_ssim_level_fwd_adj")
+
+
+def msssim_weights_striped(sums, stripes, stripe_stride, folded, levels, planes, nvalid, level_weights, ms, mix, l1_sum, l1_numel, grad_out,
+                           loss_out, wts, l1_coef):
+    L.check(L.lib().pssr_msssim_weights_striped(L.ptr(sums), stripes, C.c_int64(stripe_stride), L.ptr(folded), levels, planes, L.ptr(nvalid),
+                                                L.ptr(level_weights), int(ms), C.c_float(mix), L.ptr(l1_sum), C.c_double(l1_numel),
+                                                L.ptr(grad_out), L.ptr(loss_out), L.ptr(wts), L.ptr(l1_coef), L.stream_ptr()),
+            "pssr_msssim_weights_striped")
+
+
+def ssim_level_bwd_adj(x, y, adj, planes, h, w, win, wts, dcoarse, hc, wc, l1_coef, dx):
+    k = len(win); arr = (C.c_float * k)(*win)
+    L.check(L.lib().pssr_ssim_level_bwd_adj(L.ptr(x), L.ptr(y), L.ptr(adj), planes, h, w, arr, k, L.ptr(wts), L.ptr(dcoarse), hc, wc,
+                                            L.ptr(l1_coef), L.ptr(dx), L.stream_ptr()), "pssr_ssim_level_bwd_adj")
+
+
 def avgpool2_planes(x, out, planes, h, w):
     L.check(L.lib().pssr_avgpool2_planes(L.ptr(x), L.ptr(out), planes, h, w, L.stream_ptr()), "pssr_avgpool2_planes")
 

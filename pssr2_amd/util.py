@@ -51,11 +51,22 @@ class _SSIMLossFunction(torch.autograd.Function):
             ops.avgpool2_planes(xs[-1], xo, planes, hh, ww)
             ops.avgpool2_planes(ys[-1], yo, planes, hh, ww)
             xs.append(xo), ys.append(yo), dims.append((ho, wo))
-        sums = torch.zeros(levels * planes * 2 + 2, dtype=torch.float64, device=dev)
-        l1_sum = sums[-2:-1] if mix < 1 else None
+        # training with the default 11-tap window: keep the per-position derivatives for the backward pass (ops.ssim_level_fwd_adj);
+        # that kernel spreads its sums over `stripes` copies, folded by msssim_weights_striped
+        adjs = None
+        if k == 11 and ctx.needs_input_grad[0]:
+            adjs = [torch.empty(planes * 3 * hh * ww, device=dev) for hh, ww in dims]
+        stripes = 16 if adjs is not None else 1
+        sstride = levels * planes * 2 + 2
+        sums = torch.zeros(stripes * sstride + (sstride if stripes > 1 else 0), dtype=torch.float64, device=dev)      # (+ the folded copy)
+        l1_sum = sums[sstride - 2:sstride - 1] if mix < 1 else None
         for l in range(levels):
             hh, ww = dims[l]
-            ops.ssim_level_fwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, sums[l * planes * 2:], l1_sum if l == 0 else None)
+            if adjs is not None:
+                ops.ssim_level_fwd_adj(xs[l], ys[l], planes, hh, ww, win, c1, c2, l == levels - 1, sums[l * planes * 2:],
+                                       l1_sum if l == 0 else None, stripes, sstride, adjs[l])
+            else:
+                ops.ssim_level_fwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, sums[l * planes * 2:], l1_sum if l == 0 else None)
         ckey = (tuple(dims), k, tuple(lvl_w) if ms else (1.0,), str(dev))
         cached = _CONST_CACHE.get(ckey)
         if cached is None:
@@ -66,13 +77,19 @@ class _SSIMLossFunction(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         wts = torch.empty(levels * planes, dtype=torch.float32, device=dev)
         l1c = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()), None, loss, wts, l1c)
-        ctx.saved = (xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, x.shape)
+        if stripes > 1:
+            ops.msssim_weights_striped(sums, stripes, sstride, sums[stripes * sstride:], levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()),
+                                       None, loss, wts, l1c)
+            sums = sums[stripes * sstride:]                       # the folded copy: what backward's weights pass reads
+            l1_sum = sums[levels * planes * 2:levels * planes * 2 + 1] if l1_sum is not None else None
+        else:
+            ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()), None, loss, wts, l1c)
+        ctx.saved = (xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, x.shape, adjs)
         return loss[0]
 
     @staticmethod
     def backward(ctx, grad_out):
-        xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, shape = ctx.saved
+        xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, shape, adjs = ctx.saved
         win, mix, ms, k1, k2, data_range, lvl_w = cfg
         levels = len(xs)
         dev = xs[0].device
@@ -87,8 +104,11 @@ class _SSIMLossFunction(torch.autograd.Function):
             hh, ww = dims[l]
             dx = torch.empty(planes, hh, ww, device=dev)
             use_ssim = (l == levels - 1)
-            ops.ssim_level_bwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, wts[l * planes:], use_ssim, dcoarse, hc, wc,
-                               l1c if (l == 0 and l1_sum is not None) else None, dx)
+            l1_arg = l1c if (l == 0 and l1_sum is not None) else None
+            if adjs is not None:
+                ops.ssim_level_bwd_adj(xs[l], ys[l], adjs[l], planes, hh, ww, win, wts[l * planes:], dcoarse, hc, wc, l1_arg, dx)
+            else:
+                ops.ssim_level_bwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, wts[l * planes:], use_ssim, dcoarse, hc, wc, l1_arg, dx)
             dcoarse, hc, wc = dx, hh, ww
         return dcoarse.view(shape), None, None
 
