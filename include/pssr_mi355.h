@@ -97,6 +97,13 @@ enum {
  * (stats[stripe][2*C], stripe = workgroup index mod PSSR_STAT_STRIPES) so that thousands of workgroups do
  * not serialise on 2*C addresses; the finalisers sum the stripes. */
 #define PSSR_STAT_STRIPES 32
+/* Every statistic buffer has PSSR_STAT_ROWS = 2 x PSSR_STAT_STRIPES rows: a workgroup adds each of its f32 partial sums v to stripe
+ * s = workgroup index mod PSSR_STAT_STRIPES as TWO exact pieces -- row s gets v rounded to a multiple of 2^-20, row
+ * PSSR_STAT_STRIPES + s the remainder rounded to a multiple of 2^-64.  Sums of such pieces are exact in f64 (no rounding, hence
+ * independent of the order in which the atomics arrive) while a row stays below 2^33 resp. holds fewer than 2^10 addends; the
+ * consumers (pssr_bn_finalize, pssr_bn_bwd_coefs, pssr_f64_to_f32, ...) add the rows in a fixed order.  Training steps are therefore
+ * bit-reproducible; beyond those magnitudes the sums merely round like ordinary f64 atomics again. */
+#define PSSR_STAT_ROWS (2 * PSSR_STAT_STRIPES)
 
 enum {
     PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
@@ -121,7 +128,7 @@ typedef struct pssr_conv_desc {
     const void* aux; int32_t aux_cstride, aux_coff;
     const float* aux_scale; const float* aux_shift;      /* [cout]                              */
     const float* aux_mean; const float* aux_invstd;      /* [cout] (DGRAD_MASK + STATS)         */
-    double* stats;              /* [PSSR_STAT_STRIPES][2*cout], caller-zeroed                  */
+    double* stats;              /* [PSSR_STAT_ROWS][2*cout], caller-zeroed                     */
     /* "blocked" pixel order (log2 r, 0 = plain NHWC): pixel (y,x) of an r-times upsampled image
      * lives at ((y/r*W/r + x/r)*r*r + (y%r)*r + x%r), i.e. F.pixel_shuffle (_blocks.py:17) of an
      * NHWC tensor whose channels were ordered sub-pixel-major needs no data movement at all.    */
@@ -283,7 +290,8 @@ int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w
 int pssr_ssim_level_fwd_adj(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1,
                             float c2, int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj,
                             pssr_stream_t stream);
-/* `sums` / `l1_sum` of pssr_ssim_level_fwd_adj are `stripes` copies `stripe_stride` doubles apart (a workgroup adds to one of them:
+/* `sums` / `l1_sum` of pssr_ssim_level_fwd_adj are 2 x `stripes` copies `stripe_stride` doubles apart (a workgroup adds the two exact
+ * pieces of each of its sums -- see PSSR_STAT_ROWS -- to copy s and copy stripes + s:
  * a 512^2 x 32 level ends with 8192 workgroups); pssr_msssim_weights_striped folds them in a fixed order into `folded`
  * ([levels * planes * 2 + 1] doubles) before doing what pssr_msssim_weights does. */
 int pssr_msssim_weights_striped(const double* sums, int stripes, int64_t stripe_stride, double* folded, int levels, int planes,
@@ -479,6 +487,12 @@ int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, in
 int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co,
                        void* dact, int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin,
                        int cout, int dtype, pssr_stream_t stream);
+
+/* The same with order-independent sums (bit-reproducible training): dw_rows [PSSR_STAT_ROWS][cout * cin * 9] and bias_rows (or NULL)
+ * [PSSR_STAT_ROWS][4^blk * cin], caller-zeroed f64 statistic buffers; fold them with pssr_f64_to_f32(rows = PSSR_STAT_ROWS). */
+int pssr_head_conv_bwd_rows(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co,
+                            void* dact, int d_cs, int d_co, int blk, double* dw_rows, double* bias_rows, int n, int h, int w,
+                            int cin, int cout, int dtype, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-sheet prediction on the device (BASELINE config 5).

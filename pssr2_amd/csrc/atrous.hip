@@ -77,7 +77,7 @@ __device__ __forceinline__ void flush(const Walk& wk, int cbase, int c, float (&
         for (int s = 0; s < NS; ++s) {
             float t = 0.f;
             for (int k = tid; k < TPB; k += wk.cw) t += lds[s * TPB + k];
-            atomicAdd(dst + (long)s * c + cbase + tid, (double)t);
+            stat_add(dst + (long)s * c + cbase + tid, (long)PSSR_STAT_STRIPES * NS * c, t);
         }
     }
     __syncthreads();

@@ -187,6 +187,18 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float z) {
 
 // Pixel linearisation: plain NHWC, or "blocked" order of an r-times (r = 1<<blk) upsampled image
 // (see pssr_conv_desc in include/pssr_mi355.h).
+// One f32 partial sum into a statistic buffer [PSSR_STAT_ROWS][row_len] (include/pssr_mi355.h): `slot` addresses the element in the
+// workgroup's stripe row, `lo_off` = PSSR_STAT_STRIPES * row_len doubles further lies the same element of the remainder row.
+// Both pieces are multiples of a fixed power of two, so the f64 atomics add them without rounding: the result does not depend on
+// the order of arrival.
+__device__ __forceinline__ void stat_add(double* slot, long lo_off, float v) {
+    const double d = (double)v;
+    const double hi = __builtin_rint(d * 0x1p20) * 0x1p-20;
+    const double lo = __builtin_rint((d - hi) * 0x1p64) * 0x1p-64;
+    atomicAdd(slot, hi);
+    atomicAdd(slot + lo_off, lo);
+}
+
 __device__ __forceinline__ long pix_index(int gi, int gy, int gx, int H, int W, int blk) {
     if (blk == 0) return ((long)gi * H + gy) * W + gx;
     const int R = 1 << blk;

@@ -199,8 +199,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 #pragma unroll
             for (int w = 0; w < 4; ++w) { t1 += Red[(w * BN + tid) * 2]; t2 += Red[(w * BN + tid) * 2 + 1]; }
             double* st = p.stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * p.cout;
-            atomicAdd(st + n0 + tid, (double)t1);
-            atomicAdd(st + p.cout + n0 + tid, (double)t2);
+            const long lo = (long)PSSR_STAT_STRIPES * 2 * p.cout;
+            stat_add(st + n0 + tid, lo, t1);
+            stat_add(st + p.cout + n0 + tid, lo, t2);
         }
     }
 }
@@ -327,8 +328,9 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
 #pragma unroll
             for (int w = 0; w < 4; ++w) { t1 += Red[(w * BN + tid) * 2]; t2 += Red[(w * BN + tid) * 2 + 1]; }
             double* st = p.stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * p.cout;
-            atomicAdd(st + n0 + tid, (double)t1);
-            atomicAdd(st + p.cout + n0 + tid, (double)t2);
+            const long lo = (long)PSSR_STAT_STRIPES * 2 * p.cout;
+            stat_add(st + n0 + tid, lo, t1);
+            stat_add(st + p.cout + n0 + tid, lo, t2);
         }
     }
 }

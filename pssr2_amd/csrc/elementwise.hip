@@ -38,6 +38,7 @@ template <int NS>
 __device__ __forceinline__ void flush_sums(const ChanMap& m, int cg, float (*acc)[4], double* dst, int C, float* lds) {
     // lds: [TPB][NS*4]; dst is striped: [PSSR_STAT_STRIPES][NS*C]
     dst += (long)(blockIdx.x % PSSR_STAT_STRIPES) * NS * C;
+    const long lo_off = (long)PSSR_STAT_STRIPES * NS * C;
     if (m.cg_count <= TPB) {
         const int tid = threadIdx.x;
         if (m.active())
@@ -53,7 +54,7 @@ __device__ __forceinline__ void flush_sums(const ChanMap& m, int cg, float (*acc
                 for (int e = 0; e < 4; ++e) {
                     float t = 0.f;
                     for (int pl = 0; pl < m.ppb; ++pl) t += lds[(pl * m.cg_count + tid) * NS * 4 + s * 4 + e];
-                    atomicAdd(dst + (long)s * C + tid * 4 + e, (double)t);
+                    stat_add(dst + (long)s * C + tid * 4 + e, lo_off, t);
                 }
         }
         __syncthreads();
@@ -61,7 +62,7 @@ __device__ __forceinline__ void flush_sums(const ChanMap& m, int cg, float (*acc
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dst + (long)s * C + cg * 4 + e, (double)acc[s][e]);
+            for (int e = 0; e < 4; ++e) stat_add(dst + (long)s * C + cg * 4 + e, lo_off, acc[s][e]);
     }
 }
 
@@ -100,7 +101,7 @@ __global__ void nchw_stats_kernel(const float* __restrict__ x, int n, int c, lon
     }
     if (threadIdx.x == 0) {
         double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
-        atomicAdd(st + ch, (double)r1[0]); atomicAdd(st + c + ch, (double)r2[0]);
+        stat_add(st + ch, (long)PSSR_STAT_STRIPES * 2 * c, r1[0]); stat_add(st + c + ch, (long)PSSR_STAT_STRIPES * 2 * c, r2[0]);
     }
 }
 
@@ -135,7 +136,7 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
     const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
     const long off[2] = {i, (long)c + i};
     double sv[2];
-    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_STRIPES, i < c, sv);
+    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_ROWS, i < c, sv);
     if (i >= c || threadIdx.y != 0) return;
     const double s1 = sv[0], s2 = sv[1];
     const double mu = s1 / count;
@@ -168,7 +169,7 @@ __global__ void bn_bwd_coefs_kernel(const double* stats, double count, const flo
     const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
     const long off[2] = {i, (long)c + i};
     double sv[2];
-    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_STRIPES, i < c, sv);
+    stripe_sums<2>(stats, 2L * c, off, PSSR_STAT_ROWS, i < c, sv);
     if (i >= c || threadIdx.y != 0) return;
     const double s1 = sv[0], s2 = sv[1];
     const double c1 = s1 / count, c2 = s2 / count;
@@ -240,7 +241,7 @@ __global__ void input_norm_bwd_kernel(const T* __restrict__ da, const T* __restr
     }
     if (threadIdx.x == 0) {
         double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
-        atomicAdd(st + ch, (double)r1[0]); atomicAdd(st + c + ch, (double)r2[0]);
+        stat_add(st + ch, (long)PSSR_STAT_STRIPES * 2 * c, r1[0]); stat_add(st + c + ch, (long)PSSR_STAT_STRIPES * 2 * c, r2[0]);
     }
 }
 
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(TPB) void relu_bwd_stats8_kernel(Ref dout, Ref out,
         const int g_ = j >> 4, q = j & 15;
         float t = 0.f;
         for (int k = g_; k < TPB; k += cg) t += lds[k * 16 + q];
-        atomicAdd(dst + (long)(q >> 3) * c + g_ * 8 + (q & 7), (double)t);
+        stat_add(dst + (long)(q >> 3) * c + g_ * 8 + (q & 7), (long)PSSR_STAT_STRIPES * 2 * c, t);
     }
 }
 

@@ -309,7 +309,7 @@ __device__ __forceinline__ u32x4 tr_frag(const char* a0, const char* a1) {      
 }
 
 template <typename H, int NT, bool BS, bool FULL>     // NT = cin/16; cout*9 <= 27; BS: keep the bias sums (NT = 2, 4 or 8); FULL: H, W multiples of 16
-__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void head_bwd_kernel(const HeadArgs p, int n_tiles, float* bsum, unsigned* stamps) {
+__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void head_bwd_kernel(const HeadArgs p, int n_tiles, float* bsum, unsigned* stamps, double* dw_rows, double* bs_rows) {
 #ifdef PSSR_WG_STAMPS
     unsigned long long st_prev = 0;
     unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -537,16 +537,47 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void head_bwd_kernel(const He
 #endif
 #undef HB_STAMP
 #undef HB_ISSUE
-    // ---- dW: one f32 atomic per weight and wave
+    // ---- dW: one atomic per weight and wave -- f32 onto the gradient itself, or (dw_rows) the order-independent pieces of
+    // stat_add onto a [PSSR_STAT_ROWS][cout * cin * 9] buffer that pssr_f64_to_f32 folds afterwards (bit-reproducible)
     const int kcol = lane & 31;
+    const int stripe = blockIdx.x % PSSR_STAT_STRIPES;
+    const long ndw = (long)p.cout * p.cin * 9;
 #pragma unroll
     for (int s_ = 0; s_ < CI_S; ++s_)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (m < p.cout * 9) atomicAdd(p.dw + ((long)(m / 9) * p.cin + s_ * 32 + kcol) * 9 + m % 9, accw[s_][e]);
+            if (m < p.cout * 9) {
+                const long idx = ((long)(m / 9) * p.cin + s_ * 32 + kcol) * 9 + m % 9;
+                if (dw_rows) stat_add(dw_rows + stripe * ndw + idx, PSSR_STAT_STRIPES * ndw, accw[s_][e]);
+                else atomicAdd(p.dw + idx, accw[s_][e]);
+            }
         }
-    if (BS) {
+    if (BS && bs_rows) {
+        // the bias sums of this workgroup in a fixed order (the tile buffers are free now): every thread parks its sums, an output
+        // (sub-pixel, channel) then adds its contributors by increasing pixel
+        constexpr int NPX = 256 / PPP;
+        float* bl = (float*)Pt;                  // [256][NS * 8]
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bl[tid * (NS * 8) + k * 8 + j] = bacc[k][j];
+        __syncthreads();
+        const int nsub = 1 << (2 * p.blk);
+        const long nbs = (long)nsub * C;
+        for (int o = tid; o < nsub * C; o += 256) {
+            const int sb = o / C, ch = o % C, pcq = ch / 8, j = ch % 8;
+            float t = 0.f;
+            for (int px = 0; px < NPX; ++px)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int sub = (((px / TS + k * (PXU / TS)) & bmask) << bshift) + ((px % TS) & bmask);
+                    if (sub == sb) t += bl[(px * PPP + pcq) * (NS * 8) + k * 8 + j];
+                }
+            stat_add(bs_rows + stripe * nbs + o, PSSR_STAT_STRIPES * nbs, t);
+        }
+    } else if (BS) {
         const int pix0 = tid / PPP, pc = tid % PPP;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -649,12 +680,12 @@ int pssr_head_conv_wgrad(const float* g_nchw, float g_scale, const void* act, in
 void pssr_debug_head_stamp_buffer(void* p) { g_head_stamps = (unsigned*)p; }
 #endif
 
-int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
-                       int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin, int cout, int dtype,
-                       pssr_stream_t s) {
+static int head_conv_bwd_impl(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
+                              int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, double* dw_rows, double* bias_rows, int n, int h,
+                              int w, int cin, int cout, int dtype, pssr_stream_t s) {
     int rc = check_common(act, act_cs, act_co, blk, n, h, w, cin, cout, dtype, "head_conv_bwd");
     if (rc != PSSR_OK) return rc;
-    PSSR_CHECK(g_nchw && w_oihw && dact && dw_oihw && d_cs % 8 == 0 && d_co % 8 == 0 && d_co + cin <= d_cs, PSSR_ERR_ARG, "head_conv_bwd: bad args");
+    PSSR_CHECK(g_nchw && w_oihw && dact && (dw_oihw || dw_rows) && d_cs % 8 == 0 && d_co % 8 == 0 && d_co + cin <= d_cs, PSSR_ERR_ARG, "head_conv_bwd: bad args");
     PSSR_CHECK(blk <= 2, PSSR_ERR_ARG, "head_conv_bwd: blocked order up to 4x4 sub-pixels");
     HeadArgs a{};
     a.P = act; a.p_cs = act_cs; a.p_co = act_co; a.blk = blk; a.dP = dact; a.dp_cs = d_cs; a.dp_co = d_co;
@@ -669,20 +700,35 @@ int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, 
     do {                                                                                                                \
         if (dtype == PSSR_BF16) {                                                                                       \
             (void)hipFuncSetAttribute((const void*)head_bwd_kernel<bf16_t, NT_, BS_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((head_bwd_kernel<bf16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps); \
+            hipLaunchKernelGGL((head_bwd_kernel<bf16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps, dw_rows, bias_rows); \
         } else {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)head_bwd_kernel<f16_t, NT_, BS_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((head_bwd_kernel<f16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps); \
+            hipLaunchKernelGGL((head_bwd_kernel<f16_t, NT_, BS_, FULL_>), dim3(grid), dim3(256), lds, (hipStream_t)s, a, (int)tiles, bias_sum, g_head_stamps, dw_rows, bias_rows); \
         }                                                                                                               \
     } while (0)
 #define HB(NT_, BS_) do { if (full) HB2(NT_, BS_, true); else HB2(NT_, BS_, false); } while (0)
-    PSSR_CHECK(!bias_sum || cin == 32 || cin == 64 || cin == 128, PSSR_ERR_ARG, "head_conv_bwd: bias sums need cin = 32, 64 or 128");
-    if (bias_sum) { switch (cin / 16) { case 2: HB(2, true); break; case 4: HB(4, true); break; default: HB(8, true); break; } }
+    PSSR_CHECK(!(bias_sum || bias_rows) || cin == 32 || cin == 64 || cin == 128, PSSR_ERR_ARG, "head_conv_bwd: bias sums need cin = 32, 64 or 128");
+    if (bias_sum || bias_rows) { switch (cin / 16) { case 2: HB(2, true); break; case 4: HB(4, true); break; default: HB(8, true); break; } }
     else { switch (cin / 16) { case 2: HB(2, false); break; case 4: HB(4, false); break; case 6: HB(6, false); break; default: HB(8, false); break; } }
 #undef HB
 #undef HB2
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
+}
+
+int pssr_head_conv_bwd(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
+                       int d_cs, int d_co, int blk, float* dw_oihw, float* bias_sum, int n, int h, int w, int cin, int cout, int dtype,
+                       pssr_stream_t s) {
+    return head_conv_bwd_impl(g_nchw, g_scale, w_oihw, act, act_cs, act_co, dact, d_cs, d_co, blk, dw_oihw, bias_sum, nullptr, nullptr, n, h, w,
+                              cin, cout, dtype, s);
+}
+
+int pssr_head_conv_bwd_rows(const float* g_nchw, float g_scale, const float* w_oihw, const void* act, int act_cs, int act_co, void* dact,
+                            int d_cs, int d_co, int blk, double* dw_rows, double* bias_rows, int n, int h, int w, int cin, int cout,
+                            int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dw_rows != nullptr, PSSR_ERR_ARG, "head_conv_bwd_rows: null dw_rows");
+    return head_conv_bwd_impl(g_nchw, g_scale, w_oihw, act, act_cs, act_co, dact, d_cs, d_co, blk, nullptr, nullptr, dw_rows, bias_rows, n, h, w,
+                              cin, cout, dtype, s);
 }
 
 }  // extern "C"

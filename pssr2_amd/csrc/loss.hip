@@ -135,7 +135,7 @@ __global__ void weights_kernel(const double* sums_in, int levels, int planes, co
         for (int i = threadIdx.x; i <= nvals; i += 256) {
             const double* src = i < nvals ? sums_in + i : l1_sum_in;
             double t = 0.0;
-            if (src) for (int k = 0; k < stripes; ++k) t += src[(long)k * stripe_stride];
+            if (src) for (int k = 0; k < 2 * stripes; ++k) t += src[(long)k * stripe_stride];
             folded[i] = t;
         }
         __syncthreads();
@@ -529,10 +529,11 @@ __global__ __launch_bounds__(256) void ssim_fwd_adj_k(const float* __restrict__ 
         __syncthreads();
     }
     if (tid == 0) {
-        const long so = (long)((blockIdx.x + blockIdx.y * 5) % stripes) * stripe_stride;
-        atomicAdd(sums + so + plane * 2, (double)red[0][0]);
-        atomicAdd(sums + so + plane * 2 + 1, (double)red[1][0]);
-        if (l1_sum) atomicAdd(l1_sum + so, (double)red[2][0]);
+        // (two exact pieces per sum, as stat_add: rows [0, stripes) and [stripes, 2 stripes) -- order-independent)
+        const long so = (long)((blockIdx.x + blockIdx.y * 5) % stripes) * stripe_stride, lo = (long)stripes * stripe_stride;
+        stat_add(sums + so + plane * 2, lo, red[0][0]);
+        stat_add(sums + so + plane * 2 + 1, lo, red[1][0]);
+        if (l1_sum) stat_add(l1_sum + so, lo, red[2][0]);
     }
 }
 

@@ -323,9 +323,9 @@ extern "C" int pssr_unpack_conv_wgrad_parts(const float* dwp, int parts, int row
         PSSR_LAUNCH_CHECK();
         return PSSR_OK;
     }
-    int psplit = 2048 / blocks;
-    if (psplit > parts / 4) psplit = parts / 4;
-    if (psplit < 1) psplit = 1;
+    // one subset of the parts per element: the sum order is fixed (splitting them over blockIdx.y and combining with f32 atomics was
+    // up to 2x faster on the few small weights that come here, and made the training step irreproducible)
+    int psplit = 1;
     if (psplit > 1 && !accumulate)
         hipLaunchKernelGGL(unpack_zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, m, k_pad, total);
     hipLaunchKernelGGL(unpack_kernel, dim3(blocks, psplit), dim3(256), 0, (hipStream_t)stream, dwp, parts, (long)rows * m.taps * k_pad, dw, m,

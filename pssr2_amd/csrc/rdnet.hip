@@ -637,8 +637,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Re
                     float a = 0.f, b = 0.f;
 #pragma unroll
                     for (int q = 0; q < NT / 64; ++q) { a += lds[(q * 64 + lane) * 8 + e]; b += lds[(q * 64 + lane) * 8 + 4 + e]; }
-                    atomicAdd(st + c0 + e, (double)a);
-                    atomicAdd(st + c + c0 + e, (double)b);
+                    stat_add(st + c0 + e, (long)PSSR_STAT_STRIPES * 2 * c, a);
+                    stat_add(st + c + c0 + e, (long)PSSR_STAT_STRIPES * 2 * c, b);
                 }
             }
         }

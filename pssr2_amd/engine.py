@@ -623,9 +623,17 @@ class Engine:
             grads[id(rec.conv.bias)] = gb[:self.cout]
             gw = grads[id(rec.conv.weight)] = self._gbuf(rec.conv.weight)
             # dgrad + wgrad + the bias sums of Reconstruction.pre in one pass over the HR activation
-            gpb = torch.zeros(r * r * h0, dtype=torch.float32, device=dev) if (self.blk <= 2 and h0 in (32, 64, 128)) else None
+            gpb = torch.empty(r * r * h0, dtype=torch.float32, device=dev) if (self.blk <= 2 and h0 in (32, 64, 128)) else None
             if gpb is not None:
-                ops.head_conv_bwd(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, gw, gpb, n, H, W, h0, self.cout, code)
+                # order-independent sums (ops.head_conv_bwd_rows): dW and the bias sums land in zeroed f64 statistic buffers first
+                bw.sum64.zero_()
+                if getattr(bw, "dw64", None) is None or bw.dw64.numel() != ops.STAT_STRIPES * gw.numel():
+                    bw.dw64 = torch.zeros(ops.STAT_STRIPES * gw.numel(), dtype=torch.float64, device=dev)
+                else:
+                    bw.dw64.zero_()
+                ops.head_conv_bwd_rows(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, bw.dw64, bw.sum64, n, H, W, h0, self.cout, code)
+                ops.f64_to_f32(bw.dw64, gw)
+                ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * gpb.numel()], gpb)
             else:
                 ops.head_conv_wgrad(dout, 128.0, pre_hr, self.blk, gw, n, H, W, h0, self.cout, code)
                 ops.head_conv_dgrad(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, n, H, W, h0, self.cout, code)

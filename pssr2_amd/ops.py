@@ -215,7 +215,7 @@ def clip_u8(x, out):
     L.check(L.lib().pssr_clip_u8(L.ptr(x), L.ptr(out), C.c_int64(x.numel()), L.stream_ptr()), "pssr_clip_u8")
 
 
-STAT_STRIPES = 32     # PSSR_STAT_STRIPES
+STAT_STRIPES = 64     # PSSR_STAT_ROWS: rows of every statistic buffer (32 stripes x {multiple-of-2^-20 part, remainder})
 
 
 def f64_to_f32(src, dst, accumulate=False, stripes=STAT_STRIPES):
@@ -459,6 +459,12 @@ def head_conv_bwd(g, g_scale, weight, act, dact, blk, dw, bias_sum, n, h, w, cin
     """dgrad + wgrad (+ the bias sums of the pixel-shuffle conv in front) in one pass over the activation."""
     L.check(L.lib().pssr_head_conv_bwd(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
                                        blk, L.ptr(dw), L.ptr(bias_sum), n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_bwd")
+
+
+def head_conv_bwd_rows(g, g_scale, weight, act, dact, blk, dw_rows, bias_rows, n, h, w, cin, cout, dtype):
+    """head_conv_bwd with order-independent sums: dw_rows / bias_rows are zeroed f64 [STAT_STRIPES (rows)][...] buffers, folded by f64_to_f32."""
+    L.check(L.lib().pssr_head_conv_bwd_rows(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
+                                            blk, L.ptr(dw_rows), L.ptr(bias_rows), n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_bwd_rows")
 
 
 def crappify_saltpepper(x, amount, gain, spread, seed, tile_offset, flags, out=None, tile_counter=None):

@@ -58,7 +58,8 @@ class _SSIMLossFunction(torch.autograd.Function):
             adjs = [torch.empty(planes * 3 * hh * ww, device=dev) for hh, ww in dims]
         stripes = 16 if adjs is not None else 1
         sstride = levels * planes * 2 + 2
-        sums = torch.zeros(stripes * sstride + (sstride if stripes > 1 else 0), dtype=torch.float64, device=dev)      # (+ the folded copy)
+        rows = 2 * stripes if stripes > 1 else 1        # the striped kernel adds every sum as two exact pieces (order-independent)
+        sums = torch.zeros(rows * sstride + (sstride if stripes > 1 else 0), dtype=torch.float64, device=dev)      # (+ the folded copy)
         l1_sum = sums[sstride - 2:sstride - 1] if mix < 1 else None
         for l in range(levels):
             hh, ww = dims[l]
@@ -78,9 +79,9 @@ class _SSIMLossFunction(torch.autograd.Function):
         wts = torch.empty(levels * planes, dtype=torch.float32, device=dev)
         l1c = torch.empty(1, dtype=torch.float32, device=dev)
         if stripes > 1:
-            ops.msssim_weights_striped(sums, stripes, sstride, sums[stripes * sstride:], levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()),
+            ops.msssim_weights_striped(sums, stripes, sstride, sums[rows * sstride:], levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()),
                                        None, loss, wts, l1c)
-            sums = sums[stripes * sstride:]                       # the folded copy: what backward's weights pass reads
+            sums = sums[rows * sstride:]                          # the folded copy: what backward's weights pass reads
             l1_sum = sums[levels * planes * 2:levels * planes * 2 + 1] if l1_sum is not None else None
         else:
             ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()), None, loss, wts, l1c)
