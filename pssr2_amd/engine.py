@@ -436,6 +436,7 @@ class Engine:
         b.dz = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
         b.dy = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
         b.dy2 = [buf(*p.dims[l], hid[l]) for l in range(Lv)] if self.side_wgrad else b.dy
+        b.dy3 = [buf(*p.dims[l], hid[l]) for l in range(Lv)] if self.side_wgrad else b.dy
         b.g = [buf(*p.dims[l], hid[l]) for l in range(Lv)]
         b.dout = [buf(*p.dims[l], hid[l]) for l in range(Lv)]            # gradient of a block output at level l
         b.dcat = [buf(*p.dims[l], hid[l + 1] // 4 + hid[l]) for l in range(Lv - 1)]
@@ -728,7 +729,11 @@ class Engine:
         count = float(npix)
         nl = len(blk.y)
         dz, g = bw.dz[lvl], bw.g[lvl]
-        dy, dy_alt = bw.dy[lvl], (bw.dy2[lvl] if self._side_on else bw.dy[lvl])     # ping-pong: a side-stream wgrad may still read the other one
+        # a ring of three: side-stream wgrads may still read the two older ones (with two buffers the launch stream waited for the
+        # weight gradient of the layer before at every layer: ~9 us of cross-queue signalling each time in the kernel trace)
+        ring = [bw.dy[lvl], bw.dy2[lvl], bw.dy3[lvl]] if self._side_on else [bw.dy[lvl]]
+        ri = 0
+        dy = ring[0]
         last = blk.bn[-1]
         bn_last = module.conv[3 * (nl - 1) + 1]
         self._before_write(dz)
@@ -751,9 +756,11 @@ class Engine:
             dgam, dbet = self._gbuf(bn_prev.weight), self._gbuf(bn_prev.bias)
             self.bn_coefs(prev.bstats, count, bn_prev.weight, prev.mean, prev.invstd, prev.ca, prev.cb, prev.cc, dgam, dbet)
             grads[id(bn_prev.weight)], grads[id(bn_prev.bias)] = dgam, dbet
-            self._before_write(dy_alt)
-            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_alt, npix, blk.c, code)
-            dy, dy_alt = dy_alt, dy
+            ri = (ri + 1) % len(ring)
+            dy_nxt = ring[ri]
+            self._before_write(dy_nxt)
+            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_nxt, npix, blk.c, code)
+            dy = dy_nxt
         conv0, rp = module.conv[0], module.respass
         if first:
             self._wgrad(p, grads, conv0, dy, blk.c, src, cin, 1, mode=2, hh=hh, ww=ww)
