@@ -244,6 +244,7 @@ class RDEngine(Engine):
         b.dz = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dy = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dy2 = [buf(*p.dims[k], hid[k]) for k in range(nd)] if self.side_wgrad else b.dy
+        b.dy3 = [buf(*p.dims[k], hid[k]) for k in range(nd)] if self.side_wgrad else b.dy
         b.g = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dout = [buf(*p.dims[k], hid[k]) for k in range(nd)]
         b.dcat = [buf(*p.dims[k], p.shuf_c[k] + m.skips[k]) for k in range(nd)]
