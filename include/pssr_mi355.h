@@ -287,9 +287,9 @@ int pssr_ssim_level_bwd(const float* x, const float* y, int planes, int h, int w
  * (use_ssim: the last MS-SSIM level / plain SSIM) -- and the backward filters those three maps instead of recomputing the five
  * forward maps on a 20-pixel-wider halo first (78 k instead of 295 k multiply-adds per 32 x 32 tile).  Same values as the pair above
  * up to the rounding of one reassociated product. */
-int pssr_ssim_level_fwd_adj(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1,
-                            float c2, int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj,
-                            pssr_stream_t stream);
+int pssr_ssim_level_fwd_adj(const float* x, const float* y, float in_div, int planes, int h, int w, const float* win_host, int k,
+                            float c1, float c2, int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride,
+                            float* adj, pssr_stream_t stream);
 /* `sums` / `l1_sum` of pssr_ssim_level_fwd_adj are 2 x `stripes` copies `stripe_stride` doubles apart (a workgroup adds the two exact
  * pieces of each of its sums -- see PSSR_STAT_ROWS -- to copy s and copy stripes + s:
  * a 512^2 x 32 level ends with 8192 workgroups); pssr_msssim_weights_striped folds them in a fixed order into `folded`
@@ -298,9 +298,14 @@ int pssr_msssim_weights_striped(const double* sums, int stripes, int64_t stripe_
                                 const double* nvalid, const float* level_weights, int ms, float mix, const double* l1_sum,
                                 double l1_numel, const float* grad_out, float* loss_out, float* wts, float* l1_coef,
                                 pssr_stream_t stream);
-int pssr_ssim_level_bwd_adj(const float* x, const float* y, const float* adj, int planes, int h, int w, const float* win_host,
-                            int k, const float* wts, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx,
-                            pssr_stream_t stream);
+int pssr_ssim_level_bwd_adj(const float* x, const float* y, float in_div, const float* adj, int planes, int h, int w,
+                            const float* win_host, int k, const float* wts, const float* dcoarse, int hc, int wc,
+                            const float* l1_coef, float* dx, pssr_stream_t stream);
+/* in_div (1 = none): the pair works on x / in_div and y / in_div (as torch evaluates `hr_hat / 255` of pssr/train.py:101: a
+ * multiplication by the f32 reciprocal)
+ * without those tensors existing, and dx is the gradient wrt the UNdivided x; pssr_avgpool2_planes_div makes the next level's inputs
+ * from the undivided level-0 maps the same way. */
+int pssr_avgpool2_planes_div(const float* in, float in_div, float* out, int planes, int h, int w, pssr_stream_t stream);
 
 /* torch.optim.AdamW step (decoupled weight decay) over flat f32 buffers; `step` is 1-based. */
 int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

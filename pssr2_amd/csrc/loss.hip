@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
 }
 
 // avg_pool2d(kernel 2, stride 2, padding = size % 2, count_include_pad) on planes
-__global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W, int HO, int WO) {
+__global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W, int HO, int WO, float in_mul) {
+#pragma clang fp contract(off)          // the scaled inputs are rounded products (what the quotient tensor would hold), not FMA operands
     const int py = H & 1, px = W & 1;
     const long total = (long)planes * HO * WO;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -116,7 +117,7 @@ __global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int y = 2 * oy - py + dy, x = 2 * ox - px + dx;
-                if (y >= 0 && y < H && x >= 0 && x < W) s += src[(long)y * W + x];
+                if (y >= 0 && y < H && x >= 0 && x < W) s += __fmul_rn(src[(long)y * W + x], in_mul);      // (a rounded product, as the quotient tensor would hold: no FMA contraction)
             }
         out[i] = 0.25f * s;
     }
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ X, c
 template <int K>
 __global__ __launch_bounds__(256) void ssim_fwd_adj_k(const float* __restrict__ X, const float* __restrict__ Y, int H, int W,
                                                       Win win, float C1, float C2, double* sums, double* l1_sum, int stripes, long stripe_stride,
-                                                      float* __restrict__ adj, int use_ssim) {
+                                                      float* __restrict__ adj, int use_ssim, float in_mul) {
     constexpr int halo = K - 1, IN = TS + halo, SEG = 8, NS = TS / SEG;
     constexpr int HPW = TS + 1;
     extern __shared__ float lds[];
@@ -436,7 +437,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_adj_k(const float* __restrict__ 
         const int r = i / IN, c = i % IN;
         const int gy = oy0 + r, gx = ox0 + c;
         float xv = 0.f, yv = 0.f;
-        if (gy < H && gx < W) { xv = xp[(long)gy * W + gx]; yv = yp[(long)gy * W + gx]; }
+        // (in_mul = 1 / divisor in f32: the loss of x / divisor and y / divisor without materialising the quotients -- train_paired
+        // passes images / 255, two full passes over 33 MB tensors per step and a third one for the gradient; torch divides a tensor
+        // by a scalar as a multiplication by the f32 reciprocal, so do these kernels)
+        if (gy < H && gx < W) { xv = __fmul_rn(xp[(long)gy * W + gx], in_mul); yv = __fmul_rn(yp[(long)gy * W + gx], in_mul); }
         xs[i] = xv; ys[i] = yv;
     }
     __syncthreads();
@@ -547,7 +551,7 @@ template <int K>
 __global__ __launch_bounds__(256) void ssim_bwd_adj_k(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ ADJ,
                                                       int H, int W, Win win, const float* __restrict__ wts,
                                                       const float* __restrict__ dcoarse, int HC, int WC, const float* l1_coef_p,
-                                                      float* __restrict__ dX) {
+                                                      float* __restrict__ dX, float in_mul) {
     constexpr int halo = K - 1, AD = TS + halo;
     constexpr int SEG = 8, NS = TS / SEG;
     constexpr int ADC = AD + 1;                            // row pitch of the adjoint tile (odd: the rows of a lane group on different banks)
@@ -586,8 +590,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_adj_k(const float* __restrict__ 
     for (int o = 0; o < SEG; ++o) {
         const int gy = qy0 + vr0 + o, gx = qx0 + vc;
         const bool ok = vitem && gy < H && gx < W;
-        xv[o] = ok ? xp[(long)gy * W + gx] : 0.f;
-        yv[o] = ok ? yp[(long)gy * W + gx] : 0.f;
+        xv[o] = ok ? __fmul_rn(xp[(long)gy * W + gx], in_mul) : 0.f;
+        yv[o] = ok ? __fmul_rn(yp[(long)gy * W + gx], in_mul) : 0.f;
         gsum[o] = 0.f;
     }
 #pragma unroll
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_adj_k(const float* __restrict__ 
             const float d = xv[o] - yv[o];
             g += l1c * sy * sx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         }
-        dxp[(long)gy * W + gx] = g;
+        dxp[(long)gy * W + gx] = __fmul_rn(g, in_mul);      // chain rule of x * in_mul (what autograd does for x / divisor)
     }
 }
 
@@ -861,37 +865,42 @@ int pssr_ssim_level_fwd(const float* x, const float* y, int planes, int h, int w
     return PSSR_OK;
 }
 
-int pssr_ssim_level_fwd_adj(const float* x, const float* y, int planes, int h, int w, const float* win_host, int k, float c1, float c2,
-                            int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj, pssr_stream_t s) {
+int pssr_ssim_level_fwd_adj(const float* x, const float* y, float in_div, int planes, int h, int w, const float* win_host, int k, float c1,
+                            float c2, int use_ssim, double* sums, double* l1_sum, int stripes, int64_t stripe_stride, float* adj,
+                            pssr_stream_t s) {
     PSSR_CHECK(x && y && sums && win_host && planes > 0 && adj && k == 11, PSSR_ERR_ARG,
                "ssim_level_fwd_adj: needs the adjoint buffer and the 11-tap window (k=%d)", k);
-    PSSR_CHECK(h >= k && w >= k && stripes >= 1 && (stripes == 1 || stripe_stride > 0), PSSR_ERR_ARG, "ssim_level_fwd_adj: bad size / stripes");
+    PSSR_CHECK(h >= k && w >= k && stripes >= 1 && (stripes == 1 || stripe_stride > 0) && in_div > 0.f, PSSR_ERR_ARG, "ssim_level_fwd_adj: bad size / stripes / in_div");
     const int IN = TS + k - 1;
     const size_t lds = (size_t)(2 * IN * IN + IN * (TS + 1)) * sizeof(float);
     const int eh = l1_sum ? h : h - k + 1, ew = l1_sum ? w : w - k + 1;
     hipLaunchKernelGGL(ssim_fwd_adj_k<11>, dim3(cdiv(ew, TS), cdiv(eh, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, h, w,
-                       make_win(win_host, k), c1, c2, sums, l1_sum, stripes, (long)stripe_stride, adj, use_ssim);
+                       make_win(win_host, k), c1, c2, sums, l1_sum, stripes, (long)stripe_stride, adj, use_ssim, in_div == 1.f ? 1.f : 1.f / in_div);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
 
-int pssr_ssim_level_bwd_adj(const float* x, const float* y, const float* adj, int planes, int h, int w, const float* win_host, int k,
-                            const float* wts, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx, pssr_stream_t s) {
+int pssr_ssim_level_bwd_adj(const float* x, const float* y, float in_div, const float* adj, int planes, int h, int w, const float* win_host,
+                            int k, const float* wts, const float* dcoarse, int hc, int wc, const float* l1_coef, float* dx, pssr_stream_t s) {
     PSSR_CHECK(x && y && adj && wts && dx && win_host && planes > 0 && k == 11, PSSR_ERR_ARG, "ssim_level_bwd_adj: bad args (k=%d)", k);
     constexpr int AD = TS + 10;
     const size_t lds = (size_t)(AD * (AD + 1) + (AD + 8) * (TS + 1)) * sizeof(float);
     hipLaunchKernelGGL(ssim_bwd_adj_k<11>, dim3(cdiv(w, TS), cdiv(h, TS), planes), dim3(256), lds, (hipStream_t)s, x, y, adj, h, w,
-                       make_win(win_host, k), wts, dcoarse, hc, wc, l1_coef, dx);
+                       make_win(win_host, k), wts, dcoarse, hc, wc, l1_coef, dx, in_div == 1.f ? 1.f : 1.f / in_div);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
 
 int pssr_avgpool2_planes(const float* in, float* out, int planes, int h, int w, pssr_stream_t s) {
-    PSSR_CHECK(in && out && planes > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "avgpool2_planes: bad args");
+    return pssr_avgpool2_planes_div(in, 1.f, out, planes, h, w, s);
+}
+
+int pssr_avgpool2_planes_div(const float* in, float in_div, float* out, int planes, int h, int w, pssr_stream_t s) {
+    PSSR_CHECK(in && out && planes > 0 && h > 0 && w > 0 && in_div > 0.f, PSSR_ERR_ARG, "avgpool2_planes: bad args");
     const int ho = (h + 2 * (h & 1) - 2) / 2 + 1, wo = (w + 2 * (w & 1) - 2) / 2 + 1;
     const long total = (long)planes * ho * wo;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, in, out, planes, h, w, ho, wo);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, in, out, planes, h, w, ho, wo, in_div == 1.f ? 1.f : 1.f / in_div);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

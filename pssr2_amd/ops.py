@@ -235,9 +235,9 @@ def ssim_level_fwd(x, y, planes, h, w, win, c1, c2, sums, l1_sum=None):
                                         L.ptr(l1_sum), L.stream_ptr()), "pssr_ssim_level_fwd")
 
 
-def ssim_level_fwd_adj(x, y, planes, h, w, win, c1, c2, use_ssim, sums, l1_sum, stripes, stripe_stride, adj):
+def ssim_level_fwd_adj(x, y, planes, h, w, win, c1, c2, use_ssim, sums, l1_sum, stripes, stripe_stride, adj, in_div=1.0):
     k = len(win); arr = (C.c_float * k)(*win)
-    L.check(L.lib().pssr_ssim_level_fwd_adj(L.ptr(x), L.ptr(y), planes, h, w, arr, k, C.c_float(c1), C.c_float(c2), int(use_ssim), L.ptr(sums),
+    L.check(L.lib().pssr_ssim_level_fwd_adj(L.ptr(x), L.ptr(y), C.c_float(in_div), planes, h, w, arr, k, C.c_float(c1), C.c_float(c2), int(use_ssim), L.ptr(sums),
                                             L.ptr(l1_sum), stripes, C.c_int64(stripe_stride), L.ptr(adj), L.stream_ptr()), "pssr_ssim_level_fwd_adj")
 
 
@@ -249,14 +249,14 @@ def msssim_weights_striped(sums, stripes, stripe_stride, folded, levels, planes,
             "pssr_msssim_weights_striped")
 
 
-def ssim_level_bwd_adj(x, y, adj, planes, h, w, win, wts, dcoarse, hc, wc, l1_coef, dx):
+def ssim_level_bwd_adj(x, y, adj, planes, h, w, win, wts, dcoarse, hc, wc, l1_coef, dx, in_div=1.0):
     k = len(win); arr = (C.c_float * k)(*win)
-    L.check(L.lib().pssr_ssim_level_bwd_adj(L.ptr(x), L.ptr(y), L.ptr(adj), planes, h, w, arr, k, L.ptr(wts), L.ptr(dcoarse), hc, wc,
+    L.check(L.lib().pssr_ssim_level_bwd_adj(L.ptr(x), L.ptr(y), C.c_float(in_div), L.ptr(adj), planes, h, w, arr, k, L.ptr(wts), L.ptr(dcoarse), hc, wc,
                                             L.ptr(l1_coef), L.ptr(dx), L.stream_ptr()), "pssr_ssim_level_bwd_adj")
 
 
-def avgpool2_planes(x, out, planes, h, w):
-    L.check(L.lib().pssr_avgpool2_planes(L.ptr(x), L.ptr(out), planes, h, w, L.stream_ptr()), "pssr_avgpool2_planes")
+def avgpool2_planes(x, out, planes, h, w, in_div=1.0):
+    L.check(L.lib().pssr_avgpool2_planes_div(L.ptr(x), C.c_float(in_div), L.ptr(out), planes, h, w, L.stream_ptr()), "pssr_avgpool2_planes_div")
 
 
 def msssim_weights(sums, levels, planes, nvalid, level_weights, ms, mix, l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef):

@@ -29,7 +29,9 @@ _CONST_CACHE = {}      # small per-shape device constants (kept out of hipGraph 
 
 class _SSIMLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, cfg):
+    def forward(ctx, x, y, cfg, in_div=1.0):
+        """in_div != 1: the loss of (x / in_div, y / in_div) with the divisions done inside the training kernels (11-tap window, x needing a
+        gradient); the returned gradient is wrt the undivided x."""
         if not x.is_cuda:
             raise RuntimeError("pssr2_amd.SSIMLoss runs on an MI355X (HIP) device only; there is no CPU fallback")
         win, mix, ms, k1, k2, data_range, lvl_w = cfg
@@ -42,14 +44,18 @@ class _SSIMLossFunction(torch.autograd.Function):
             raise AssertionError(f"Image size should be larger than {(k - 1) * 2 ** 4} due to the 4 downsamplings in ms-ssim")
         c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
         dev = x.device
+        fused_div = in_div != 1.0 and k == 11 and ctx.needs_input_grad[0]
+        if in_div != 1.0 and not fused_div:             # the plain kernels take the quotients as tensors
+            x, y = x / in_div, y / in_div
+        div0 = in_div if fused_div else 1.0
         xs, ys, dims = [x], [y], [(h, w)]
-        for _ in range(1, levels):
+        for lv in range(1, levels):
             hh, ww = dims[-1]
             ho, wo = (hh + 2 * (hh & 1) - 2) // 2 + 1, (ww + 2 * (ww & 1) - 2) // 2 + 1
             xo = torch.empty(planes, ho, wo, device=dev)
             yo = torch.empty(planes, ho, wo, device=dev)
-            ops.avgpool2_planes(xs[-1], xo, planes, hh, ww)
-            ops.avgpool2_planes(ys[-1], yo, planes, hh, ww)
+            ops.avgpool2_planes(xs[-1], xo, planes, hh, ww, div0 if lv == 1 else 1.0)
+            ops.avgpool2_planes(ys[-1], yo, planes, hh, ww, div0 if lv == 1 else 1.0)
             xs.append(xo), ys.append(yo), dims.append((ho, wo))
         # training with the default 11-tap window: keep the per-position derivatives for the backward pass (ops.ssim_level_fwd_adj);
         # that kernel spreads its sums over `stripes` copies, folded by msssim_weights_striped
@@ -65,7 +71,7 @@ class _SSIMLossFunction(torch.autograd.Function):
             hh, ww = dims[l]
             if adjs is not None:
                 ops.ssim_level_fwd_adj(xs[l], ys[l], planes, hh, ww, win, c1, c2, l == levels - 1, sums[l * planes * 2:],
-                                       l1_sum if l == 0 else None, stripes, sstride, adjs[l])
+                                       l1_sum if l == 0 else None, stripes, sstride, adjs[l], div0 if l == 0 else 1.0)
             else:
                 ops.ssim_level_fwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, sums[l * planes * 2:], l1_sum if l == 0 else None)
         ckey = (tuple(dims), k, tuple(lvl_w) if ms else (1.0,), str(dev))
@@ -85,12 +91,12 @@ class _SSIMLossFunction(torch.autograd.Function):
             l1_sum = sums[levels * planes * 2:levels * planes * 2 + 1] if l1_sum is not None else None
         else:
             ops.msssim_weights(sums, levels, planes, nvalid, lw, ms, mix, l1_sum, float(x.numel()), None, loss, wts, l1c)
-        ctx.saved = (xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, x.shape, adjs)
+        ctx.saved = (xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, x.shape, adjs, div0, in_div if not fused_div else 1.0)
         return loss[0]
 
     @staticmethod
     def backward(ctx, grad_out):
-        xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, shape, adjs = ctx.saved
+        xs, ys, dims, sums, nvalid, lw, l1_sum, cfg, planes, shape, adjs, div0, post_div = ctx.saved
         win, mix, ms, k1, k2, data_range, lvl_w = cfg
         levels = len(xs)
         dev = xs[0].device
@@ -107,11 +113,15 @@ class _SSIMLossFunction(torch.autograd.Function):
             use_ssim = (l == levels - 1)
             l1_arg = l1c if (l == 0 and l1_sum is not None) else None
             if adjs is not None:
-                ops.ssim_level_bwd_adj(xs[l], ys[l], adjs[l], planes, hh, ww, win, wts[l * planes:], dcoarse, hc, wc, l1_arg, dx)
+                ops.ssim_level_bwd_adj(xs[l], ys[l], adjs[l], planes, hh, ww, win, wts[l * planes:], dcoarse, hc, wc, l1_arg, dx,
+                                       div0 if l == 0 else 1.0)
             else:
                 ops.ssim_level_bwd(xs[l], ys[l], planes, hh, ww, win, c1, c2, wts[l * planes:], use_ssim, dcoarse, hc, wc, l1_arg, dx)
             dcoarse, hc, wc = dx, hh, ww
-        return dcoarse.view(shape), None, None
+        g = dcoarse.view(shape)
+        if post_div != 1.0:
+            g = g / post_div
+        return g, None, None, None
 
 
 class SSIMLoss(nn.Module):
@@ -137,6 +147,14 @@ class SSIMLoss(nn.Module):
             raise ValueError(f"Input images should have the same dimensions, but got {input.shape} and {target.shape}.")
         cfg = (self.win, float(self.mix), bool(self.ms), self.K[0], self.K[1], 1.0, self.weights)
         return _SSIMLossFunction.apply(input, target, cfg)
+
+    def forward_divided(self, input, target, divisor: float):
+        """``self(input / divisor, target / divisor)`` -- what pssr/train.py:101 computes with divisor 255 -- without the two quotient
+        tensors and the gradient's division pass: the training kernels divide on load (IEEE division, same values)."""
+        if input.shape != target.shape:
+            raise ValueError(f"Input images should have the same dimensions, but got {input.shape} and {target.shape}.")
+        cfg = (self.win, float(self.mix), bool(self.ms), self.K[0], self.K[1], 1.0, self.weights)
+        return _SSIMLossFunction.apply(input, target, cfg, float(divisor))
 
 
 def ssim(X, Y, data_range=255, win_size=11, win_sigma=1.5):

@@ -65,3 +65,30 @@ def test_fused_adamw_matches_torch():
         ref.step(), mine.step()
     for a, b in zip(ref_p, my_p):
         np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_forward_divided_equals_loss_of_quotients():
+    """SSIMLoss.forward_divided(x, y, 255) is SSIMLoss()(x / 255, y / 255) (pssr/train.py:101) with the divisions done on load inside the
+    training kernels: same loss and, for the network output, the same gradient bit for bit (IEEE division both ways)."""
+    from pssr2_amd.util import SSIMLoss
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(3, 1, 192, 200, generator=g) * 255).cuda()
+    y = (x + torch.randn(3, 1, 192, 200, generator=g).cuda() * 20).clamp(0, 255)
+    lf = SSIMLoss(mix=0.8)
+    xa = x.clone().requires_grad_(True)
+    la = lf(xa / 255, y / 255)
+    la.backward()
+    xb = x.clone().requires_grad_(True)
+    lb = lf.forward_divided(xb, y, 255)
+    lb.backward()
+    assert float(la) == float(lb)
+    assert torch.equal(xa.grad, xb.grad)
+    # windows the training kernels do not cover fall back to the quotient tensors
+    lf7 = SSIMLoss(ms=False, win_size=7)
+    xc = x.clone().requires_grad_(True)
+    lc = lf7.forward_divided(xc, y, 255)
+    lc.backward()
+    xd = x.clone().requires_grad_(True)
+    ld = lf7(xd / 255, y / 255)
+    ld.backward()
+    assert float(lc) == float(ld) and torch.equal(xc.grad, xd.grad)
