@@ -102,7 +102,7 @@ class TrainStepper:
         hr_hat = self.model(lr)
         if self.clamp:
             hr_hat = torch.clamp(hr_hat, 0, self.image_range)
-        if type(self.loss_fn).__name__ == "SSIMLoss" and hasattr(self.loss_fn, "forward_divided"):
+        if type(self.loss_fn).__name__ == "SSIMLoss" and hasattr(self.loss_fn, "forward_divided") and os.environ.get("PSSR_FUSED_DIV", "1") != "0":
             loss = self.loss_fn.forward_divided(hr_hat, hr, self.image_range)       # same values, three passes over 33 MB tensors fewer
         else:
             loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
