@@ -306,6 +306,9 @@ int pssr_ssim_level_bwd_adj(const float* x, const float* y, float in_div, const 
  * without those tensors existing, and dx is the gradient wrt the UNdivided x; pssr_avgpool2_planes_div makes the next level's inputs
  * from the undivided level-0 maps the same way. */
 int pssr_avgpool2_planes_div(const float* in, float in_div, float* out, int planes, int h, int w, pssr_stream_t stream);
+/* both pyramids of the loss (prediction and target) in one launch */
+int pssr_avgpool2_pair_div(const float* x, const float* y, float in_div, float* xo, float* yo, int planes, int h, int w,
+                           pssr_stream_t stream);
 
 /* torch.optim.AdamW step (decoupled weight decay) over flat f32 buffers; `step` is 1-based. */
 int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

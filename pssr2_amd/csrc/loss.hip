@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
 }
 
 // avg_pool2d(kernel 2, stride 2, padding = size % 2, count_include_pad) on planes
-__global__ void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W, int HO, int WO, float in_mul) {
+__global__ void avgpool_kernel(const float* __restrict__ in0, float* __restrict__ out0, const float* __restrict__ in1, float* __restrict__ out1,
+                               int planes, int H, int W, int HO, int WO, float in_mul) {
 #pragma clang fp contract(off)          // the scaled inputs are rounded products (what the quotient tensor would hold), not FMA operands
+    const float* in = blockIdx.y ? in1 : in0;          // (two tensors per launch: the x and y pyramids of the loss)
+    float* out = blockIdx.y ? out1 : out0;
     const int py = H & 1, px = W & 1;
     const long total = (long)planes * HO * WO;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -132,11 +135,22 @@ __global__ void weights_kernel(const double* sums_in, int levels, int planes, co
     const double* sums = sums_in;
     const double* l1_sum = l1_sum_in;
     if (stripes > 1) {
+        // (fixed order; the loads of a value are independent and issued together: the serial loop cost 24 us on the step's chain)
         const int nvals = levels * planes * 2;
         for (int i = threadIdx.x; i <= nvals; i += 256) {
             const double* src = i < nvals ? sums_in + i : l1_sum_in;
             double t = 0.0;
-            if (src) for (int k = 0; k < 2 * stripes; ++k) t += src[(long)k * stripe_stride];
+            if (src) {
+                int k = 0;
+                for (; k + 8 <= 2 * stripes; k += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * stripe_stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t += v[u];
+                }
+                for (; k < 2 * stripes; ++k) t += src[(long)k * stripe_stride];
+            }
             folded[i] = t;
         }
         __syncthreads();
@@ -900,7 +914,17 @@ int pssr_avgpool2_planes_div(const float* in, float in_div, float* out, int plan
     const int ho = (h + 2 * (h & 1) - 2) / 2 + 1, wo = (w + 2 * (w & 1) - 2) / 2 + 1;
     const long total = (long)planes * ho * wo;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, in, out, planes, h, w, ho, wo, in_div == 1.f ? 1.f : 1.f / in_div);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, in, out, in, out, planes, h, w, ho, wo, in_div == 1.f ? 1.f : 1.f / in_div);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_avgpool2_pair_div(const float* x, const float* y, float in_div, float* xo, float* yo, int planes, int h, int w, pssr_stream_t s) {
+    PSSR_CHECK(x && y && xo && yo && planes > 0 && h > 0 && w > 0 && in_div > 0.f, PSSR_ERR_ARG, "avgpool2_pair: bad args");
+    const int ho = (h + 2 * (h & 1) - 2) / 2 + 1, wo = (w + 2 * (w & 1) - 2) / 2 + 1;
+    const long total = (long)planes * ho * wo;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)s, x, xo, y, yo, planes, h, w, ho, wo, in_div == 1.f ? 1.f : 1.f / in_div);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

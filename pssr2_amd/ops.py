@@ -259,6 +259,11 @@ def avgpool2_planes(x, out, planes, h, w, in_div=1.0):
     L.check(L.lib().pssr_avgpool2_planes_div(L.ptr(x), C.c_float(in_div), L.ptr(out), planes, h, w, L.stream_ptr()), "pssr_avgpool2_planes_div")
 
 
+def avgpool2_pair(x, y, xo, yo, planes, h, w, in_div=1.0):
+    L.check(L.lib().pssr_avgpool2_pair_div(L.ptr(x), L.ptr(y), C.c_float(in_div), L.ptr(xo), L.ptr(yo), planes, h, w, L.stream_ptr()),
+            "pssr_avgpool2_pair_div")
+
+
 def msssim_weights(sums, levels, planes, nvalid, level_weights, ms, mix, l1_sum, l1_numel, grad_out, loss_out, wts, l1_coef):
     L.check(L.lib().pssr_msssim_weights(L.ptr(sums), levels, planes, L.ptr(nvalid), L.ptr(level_weights), int(ms), C.c_float(mix),
                                         L.ptr(l1_sum), C.c_double(l1_numel), L.ptr(grad_out), L.ptr(loss_out), L.ptr(wts),

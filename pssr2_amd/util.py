@@ -54,8 +54,7 @@ class _SSIMLossFunction(torch.autograd.Function):
             ho, wo = (hh + 2 * (hh & 1) - 2) // 2 + 1, (ww + 2 * (ww & 1) - 2) // 2 + 1
             xo = torch.empty(planes, ho, wo, device=dev)
             yo = torch.empty(planes, ho, wo, device=dev)
-            ops.avgpool2_planes(xs[-1], xo, planes, hh, ww, div0 if lv == 1 else 1.0)
-            ops.avgpool2_planes(ys[-1], yo, planes, hh, ww, div0 if lv == 1 else 1.0)
+            ops.avgpool2_pair(xs[-1], ys[-1], xo, yo, planes, hh, ww, div0 if lv == 1 else 1.0)
             xs.append(xo), ys.append(yo), dims.append((ho, wo))
         # training with the default 11-tap window: keep the per-position derivatives for the backward pass (ops.ssim_level_fwd_adj);
         # that kernel spreads its sums over `stripes` copies, folded by msssim_weights_striped
