@@ -184,7 +184,7 @@ int pssr_conv2d_wgrad_parts(const pssr_wgrad_desc* desc);
  * NHWC tensor slices are passed as (pointer, channel stride, channel offset); C % 4 == 0.
  */
 
-/* (striped, see PSSR_STAT_STRIPES) stats[0:c] += sum, stats[c:2c] += sum of squares of (x*pre_scale + pre_shift) over N,H,W of an
+/* (statistic buffer of PSSR_STAT_ROWS rows, see there) stats[0:c] += sum, stats[c:2c] += sum of squares of (x*pre_scale + pre_shift) over N,H,W of an
  * NCHW f32 tensor: batch statistics of ResUNet.norm on "x/128-1" (pssr/models/resunet.py:66-68). */
 int pssr_channel_stats_nchw(const float* x, int n, int c, int64_t hw, float pre_scale, float pre_shift,
                             double* stats, pssr_stream_t stream);
@@ -247,7 +247,7 @@ int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out,
                         void* dz, int dz_cs, int dz_co, double* stats, int64_t npix, int c, int dtype,
                         pssr_stream_t stream);
 
-/* out[stripe][c] += sum over pixels (bias gradients); out holds PSSR_STAT_STRIPES x c doubles */
+/* out[row][c] += sum over pixels (bias gradients); out is a statistic buffer of PSSR_STAT_ROWS x c doubles */
 int pssr_channel_sum_nhwc(const void* x, int cs, int co, int64_t npix, int c, double* out, int dtype,
                           pssr_stream_t stream);
 /* f32 NCHW -> NHWC in the compute dtype, scaled, channels [c, out_cs) zero (gradient of the output) */
@@ -382,7 +382,7 @@ int pssr_im2col_dil(const void* in, int in_cs, int in_co, int c, const float* sc
                     int n, int h, int w, int dil, int dtype, pssr_stream_t stream);
 /* Gradient of the above: out[pixel][ci] = sum_t dcol[pixel - off_t][t * cp + ci].  With y != NULL the ReLU mask of the
  * pre-activation (y * scale + shift > 0) is applied; with stats != NULL also stats[stripe][0:c] += sum g,
- * stats[stripe][c:2c] += sum g * (y - mean) * invstd (f64, PSSR_STAT_STRIPES stripes, caller-zeroed): the inputs of
+ * stats[stripe][c:2c] += sum g * (y - mean) * invstd (f64 statistic buffer of PSSR_STAT_ROWS rows, caller-zeroed): the inputs of
  * pssr_bn_bwd_coefs for the BatchNorm in front of the ReLU. */
 int pssr_col2im_dil(const void* dcol, int cp, void* out, int out_cs, int out_co, int c, int n, int h, int w, int dil,
                     const void* y, int y_cs, int y_co, const float* scale, const float* shift, const float* mean,
@@ -445,7 +445,7 @@ int pssr_dwconv7_wgrad_ws(const void* dy, int dy_cs, int dy_co, const void* x, i
  * (_rdnet.py:56-62) a 1x1 conv over 4*c_pad channels (weights packed with mode 4).  mean / rstd: f32 [n*h*w], kept for
  * the backward pass (NULL in inference).
  * Backward: dx (+)= rstd*(g*gamma - mean_c(g*gamma) - xhat*mean_c(g*gamma*xhat)); stats[stripe][0..C) += sum g*xhat
- * (dgamma), stats[stripe][C..2C) += sum g (dbeta), f64, PSSR_STAT_STRIPES stripes, caller-zeroed. */
+ * (dgamma), stats[stripe][C..2C) += sum g (dbeta), f64 statistic buffer of PSSR_STAT_ROWS rows, caller-zeroed. */
 int pssr_layernorm2d_fwd(const void* in, int in_cs, int in_co, const float* gamma, const float* beta, float eps, void* out,
                          int out_cs, int out_co, int s2d, int c_pad, int n, int h, int w, int c, float* mean, float* rstd,
                          int dtype, pssr_stream_t stream);

@@ -83,7 +83,7 @@ def test_reference_fixture_f32(golden, name):
         worst_cos, worst_rel, worst_l2, worst_fix = min(worst_cos, cos), max(worst_rel, rel), max(worst_l2, l2), max(worst_fix, fix_l2)
         # The gradient of these untrained nets is discontinuous in the activations: a 1e-6 change of a block input moves the gradient
         # behind a PSP block by 2 % in L2 (measured: the SAME f64 torch graph on the engine's and on the oracle's feature map,
-        # scratch/rd_flow_dbg.py) because ReLU decisions behind the chunk BatchNorms flip.  Whole-model gradients are therefore held
+        # a diagnostic script of round 2) because ReLU decisions behind the chunk BatchNorms flip.  Whole-model gradients are therefore held
         # to direction and size; the blocks themselves are pinned to 1e-5 on identical inputs (test_*_block_vs_f64_autograd below).
         assert cos > 0.999, (k, cos)
         assert l2 < max(6e-2, 3 * fix_l2), (k, l2, fix_l2)
