@@ -210,7 +210,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 // pieces = one 16-byte store per piece, and one straight-line body per epilogue kind (the generic epilogue above
 // branches on p.epi per piece and unrolls 16 passes: ~12k instructions, most of a K=576 layer's time).
 // Es columns are permuted so that both float4 halves of a piece are lane-contiguous: logical 8c+4u+e -> u*BN/2 + 4c + e.
-template <typename T, int BN, class C, int EPI, bool STATS>
+// TR: the accumulators are those of the TRANSPOSED product (weights as the MFMA's A operand, conv_v3.h): a lane holds, for ONE pixel
+// (lane & 31), channels (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of a 32-channel tile, i.e. runs of 4 consecutive channels = one
+// ds_write_b128 each (a quarter of the LDS write instructions of the plain layout, whose 128 scalar writes per lane were most of a
+// K = 576 layer's epilogue).  Rows are then BN + 4 floats apart (the 16 lanes of a write group hit 16 different bank quads).
+template <typename T, int BN, class C, int EPI, bool STATS, bool TR = false>
 __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
     using X = TT<T>;
     static_assert(sizeof(T) == 2, "8-channel pieces are 16 bytes of a 16-bit type");
@@ -220,6 +224,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     float* Es = (float*)smem;
     float* Red = (float*)(smem + C::E_BYTES);       // [4 waves][BN][2]
     constexpr int CG = BN / 8, RP = 256 / CG;       // pieces per row, rows per pass
+    constexpr int EP = TR ? BN + 4 : BN;            // floats between rows of Es
     constexpr int ROWS = C::WM * 32, PASSES = ROWS / RP;
     static_assert(PASSES >= 1 && ROWS % RP == 0, "pass geometry");
     int wcol[C::NJ];
@@ -230,15 +235,31 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     }
     // row tile 0 leaves its registers before the per-channel constants are loaded (with 128 accumulators per lane the
     // epilogue otherwise spills)
+    auto es_write = [&](int mi) {
+        if constexpr (TR) {
 #pragma unroll
-    for (int nj = 0; nj < C::NJ; ++nj)
+            for (int nj = 0; nj < C::NJ; ++nj)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            Es[row * BN + wcol[nj]] = acc[0][nj][e];
+                for (int q = 0; q < 4; ++q) {       // channels 8 (c) + 4 h + (0..3), c = (wn NJ + nj) 4 + q  ->  column h BN/2 + 4 c
+                    const int c = (wn * C::NJ + nj) * 4 + q;
+                    *(float4*)(Es + (wm * 32 + r) * EP + h * (BN / 2) + 4 * c) =
+                        make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
+                }
+        } else {
+#pragma unroll
+            for (int nj = 0; nj < C::NJ; ++nj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    Es[row * EP + wcol[nj]] = acc[mi][nj][e];
+                }
         }
+    };
+    es_write(0);
     asm volatile("" ::: "memory");
-    const int c8 = tid % CG, row0 = tid / CG;
+    // TR, 8 pieces per row: the two rows of a 16-lane read group are 8 apart (8 x (BN + 4) floats = 128 bytes mod 256: no shared bank)
+    const int c8 = tid % CG, rs = tid / CG;
+    const int row0 = (TR && CG == 8) ? ((rs >> 1) & 7) + ((rs & 1) << 3) + ((rs >> 4) << 4) : rs;
     const int n_base = n0 + c8 * 8;
     const bool n_ok = n_base < p.cout;
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs[8], xh[8], xm[8], xi[8];
@@ -266,13 +287,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     for (int mi = 0; mi < C::MI; ++mi) {
         if (mi) {
             __syncthreads();
-#pragma unroll
-            for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    Es[row * BN + wcol[nj]] = acc[mi][nj][e];
-                }
+            es_write(mi);
         }
         __syncthreads();
 #pragma unroll 1
@@ -283,8 +298,8 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
             const int gy = y0 + ty, gx = x0 + tx, gi = img0 + img;
             if (!(n_ok && gi < p.N && gy < p.H && gx < p.W)) continue;
             float v[8];
-            load4(Es + row * BN + c8 * 4, v);
-            load4(Es + row * BN + BN / 2 + c8 * 4, v + 4);
+            load4(Es + row * EP + c8 * 4, v);
+            load4(Es + row * EP + BN / 2 + c8 * 4, v + 4);
             float a[8];
             if (EPI != PSSR_EPI_STORE) {
                 const u32x4 araw = *(const u32x4*)(auxp + pix_index(gi, gy, gx, p.H, p.W, p.aux_blk) * p.aux_cs);
@@ -337,22 +352,22 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
 
 // picks the straight-line 8-channel epilogue when the layout allows (p.epi8, set by the host), else the generic one
 // the straight-line 8-channel epilogue of p.epi (16-bit storage, p.epi8 layouts only)
-template <typename T, int BN, class C>
+template <typename T, int BN, class C, bool TR = false>
 __device__ __forceinline__ void conv_epilogue8_any(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
     const bool st = p.flags & PSSR_FLAG_STATS;
     switch (p.epi) {
     case PSSR_EPI_STORE:
-        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, true>(p, acc, smem, tid, x0, y0, img0, n0);
-        else conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, true, TR>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false, TR>(p, acc, smem, tid, x0, y0, img0, n0);
         return;
-    case PSSR_EPI_TAIL: conv_epilogue8<T, BN, C, PSSR_EPI_TAIL, false>(p, acc, smem, tid, x0, y0, img0, n0); return;
+    case PSSR_EPI_TAIL: conv_epilogue8<T, BN, C, PSSR_EPI_TAIL, false, TR>(p, acc, smem, tid, x0, y0, img0, n0); return;
     case PSSR_EPI_DGRAD_MASK:
-        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, true>(p, acc, smem, tid, x0, y0, img0, n0);
-        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, true, TR>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_MASK, false, TR>(p, acc, smem, tid, x0, y0, img0, n0);
         return;
     default:
-        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, true>(p, acc, smem, tid, x0, y0, img0, n0);
-        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, false>(p, acc, smem, tid, x0, y0, img0, n0);
+        if (st) conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, true, TR>(p, acc, smem, tid, x0, y0, img0, n0);
+        else conv_epilogue8<T, BN, C, PSSR_EPI_DGRAD_GELU, false, TR>(p, acc, smem, tid, x0, y0, img0, n0);
         return;
     }
 }
@@ -1106,7 +1121,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish3_kernel(const ConvArgs
                     acc[mi][nj][4 * q] += v.x; acc[mi][nj][4 * q + 1] += v.y; acc[mi][nj][4 * q + 2] += v.z; acc[mi][nj][4 * q + 3] += v.w;
                 }
     }
-    conv_epilogue8_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
+    conv_epilogue8_any<T, BN, C, true>(p, acc, smem, tid, x0, y0, img0, n0);
 }
 
 // v3 launch: 16x16-pixel x 128-channel tiles; split-K when the tiles leave more than half of the 512 workgroup slots empty

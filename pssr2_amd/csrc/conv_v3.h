@@ -45,7 +45,7 @@ template <int BN> struct Cfg3 {
     static constexpr int NP = (NPIECE + 3) / 4;                           // pieces a wave issues per stage (3 / 2; BN = 64: two of the 8 are duplicates)
     static constexpr int B0 = 2 * A_BYTES;
     static constexpr int MAIN_BYTES = B0 + 3 * B_STAGE;                   // 57600 / 57600
-    static constexpr int E_BYTES = WM * 32 * BN * 4, RED_BYTES = 4 * BN * 2 * 4;
+    static constexpr int E_BYTES = WM * 32 * (BN + 4) * 4, RED_BYTES = 4 * BN * 2 * 4;     // epilogue rows are BN + 4 floats apart (conv_epilogue8, TR)
     static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
     static constexpr int PERM = BN == 128 ? 1 : 2;
     // byte offset (within a plane) of accumulator row tile mi of a wave: image rows 2 mi (BN = 128); row pair mi >> 1, column half mi & 1 (BN = 64)
@@ -65,7 +65,9 @@ template <int BN> struct Cfg3 {
 #define V3_AMI_3 "%c26"
 #define V3_RA(D, MI_, KX) "ds_read_b128 %" #D ", %20 offset:%c22+" V3_AMI_##MI_ "+" #KX "*16\n\t"
 #define V3_RB(D, NJ_, KX) "ds_read_b128 %" #D ", %21 offset:%c27+" #KX "*%c28+" #NJ_ "*1024\n\t"
-#define V3_MM(OP, ACC, A, B) OP " %" #ACC ", %" #A ", %" #B ", %" #ACC "\n\t"
+// (the weights are the MFMA's A operand: the accumulators hold the transposed product, 4 consecutive channels of one pixel per
+// register quad -- what conv_epilogue8<..., TR = true> writes to LDS with one ds_write_b128)
+#define V3_MM(OP, ACC, A, B) OP " %" #ACC ", %" #B ", %" #A ", %" #ACC "\n\t"
 #define V3_READ0(KXA, KXB) V3_RA(8, 0, KXA) V3_RB(12, 0, KXB) V3_RB(13, 1, KXB) V3_RA(9, 1, KXA) V3_RA(10, 2, KXA) V3_RA(11, 3, KXA)
 // 8 MFMAs on set 0 with the reads of tap KX into set 1 between them (and vice versa)
 #define V3_TAP01(OP, KX)                                                                     \
@@ -128,6 +130,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int h = lane >> 5, r = lane & 31;
+#ifdef PSSR_V3_STAMPS
+    unsigned long long st_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
+#endif
 
     const int bid = blockIdx.x;
     const int tn = bid % p.tiles_n;
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
         for (int i = 0; i < 5; ++i) q[i] = st_sum[i];
         q[5] = nst;
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        q[6] = xcc; q[7] = (unsigned)(st_prev & 0xffffffffu);
+        (void)xcc;
+        q[6] = (unsigned)(st_t0 & 0xffffffffu); q[7] = (unsigned)(st_prev & 0xffffffffu);      // kernel entry, end of the main loop
     }
 #endif
     // the accumulators were last written by MFMAs inside an asm statement: cover their latency before anything reads them
@@ -392,7 +399,18 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
                     dst[((mi * C::NJ + nj) * 4 + q) * 256] = make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
         return;
     }
-    conv_epilogue8_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
+    conv_epilogue8_any<T, BN, C, true>(p, acc, smem, tid, x0, y0, img0, n0);
+#ifdef PSSR_V3_STAMPS
+    if (p.stamps) {                          // second half of the buffer: [0] epilogue instructions done, [1] its stores acknowledged
+        unsigned long long t1, t2;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+        if (lane == 0) {
+            unsigned* q = p.stamps + (long)gridDim.x * gridDim.y * 32 + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 2;
+            q[0] = (unsigned)(t1 & 0xffffffffu); q[1] = (unsigned)(t2 & 0xffffffffu);
+        }
+    }
+#endif
 }
 
 }  // namespace

@@ -211,11 +211,10 @@ class TrainStepper:
                 g1.capture_begin(pool=pool)
                 state["g"] = g1
                 hr, lr = self.dataset.device_batch(self.cur.next_rows())
-                hr_hat = self.model(lr)
-                if self.clamp:
-                    hr_hat = torch.clamp(hr_hat, 0, self.image_range)
+                raw = self.model(lr)
+                hr_hat = torch.clamp(raw, 0, self.image_range) if self.clamp else raw     # (the engine gets d loss / d raw: through the clamp)
                 loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
-                (dout,) = torch.autograd.grad(loss * self.scale_dev if self.scale_dev is not None else loss, hr_hat)
+                (dout,) = torch.autograd.grad(loss * self.scale_dev if self.scale_dev is not None else loss, raw)
                 eng.backward(dout, split_cb=switch)
                 if state["g"] is not g2:
                     raise RuntimeError("the engine's backward did not reach its split point")

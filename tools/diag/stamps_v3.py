@@ -27,12 +27,12 @@ for name, H, W, ci, co, c1, pro in layers:
     if pro:
         kw.update(pro_scale=sc, pro_shift=sh, flags=L.FLAG_STATS, stats=stats)
     nblk = (H // 16) * (W // 16) * N * (co // 128)
-    buf = torch.zeros(nblk * 4 * 8, dtype=torch.int32, device="cuda")
+    buf = torch.zeros(nblk * 4 * 10, dtype=torch.int32, device="cuda")       # 8 per wave + 2 per wave (epilogue times) behind them
     lib.pssr_debug_stamp_buffer(L.ptr(buf))
     for _ in range(3):
         ops.conv2d(x, ci, pw, out, co, n=N, h=H, w=W, bias=bias, **kw)
     torch.cuda.synchronize()
-    b = buf.view(nblk, 4, 8).cpu().long()
+    b = buf[:nblk * 32].view(nblk, 4, 8).cpu().long()
     nst = int(b[0, 0, 5])
     seg = b[:, :, :5].float()
     tot = seg[:, :, :4].sum(-1)
