@@ -456,6 +456,12 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
  * EffectiveSEModule (x.mean((2,3))) and the per-image reductions of its backward.  f32 atomics, caller zeroes. */
 int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c,
                            float scale, float* out, int dtype, pssr_stream_t stream);
+/* The same with run-to-run identical bits: the workgroups of an image leave their partial sums in `workspace`
+ * (pssr_image_channel_dot_workspace_bytes; its last n words are tickets: zero before the first use, left zero by every call) and the last
+ * one to arrive adds them to `out` in a fixed order.  One call at a time per workspace.  workspace == NULL: the atomic version. */
+int64_t pssr_image_channel_dot_workspace_bytes(int n, int hw, int c);
+int pssr_image_channel_dot_ws(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c,
+                              float scale, float* out, int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t stream);
 /* EffectiveSEModule gate: u = fc(s) (1x1 conv on the [N, C] means), gate = hard_sigmoid(u) = relu6(u + 3)/6. */
 int pssr_ese_gate(const float* s_mean, const float* w_fc, const float* b_fc, int n, int c, float* u, float* gate,
                   pssr_stream_t stream);

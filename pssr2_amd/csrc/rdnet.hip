@@ -647,9 +647,13 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Re
 
 // ------------------------------------------------------------------------------------------------
 // out[img][c] += scale * sum_{p in img} a[p, c] * (b ? b[p, c] : 1);  grid = (chunks, images)
+// With `part` (workspace [images][gridDim.x][c] + one ticket word per image behind it) the workgroups of an image store their partial
+// sums instead of adding them atomically, and the one that draws the last ticket adds them to `out` in workgroup order: the same bits
+// on every run.  The ticket words are zero before and after the launch.
 template <typename T>
-__global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scale, float* __restrict__ out) {
+__global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scale, float* __restrict__ out, float* __restrict__ part) {
     __shared__ float lds[TPB * 4];
+    __shared__ int last_flag;
     const int cgc = c / 4, img = blockIdx.y;
     const int ppb = cgc <= TPB ? TPB / cgc : 1;
     const long base = (long)img * hw;
@@ -680,13 +684,32 @@ __global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scal
                 for (int e = 0; e < 4; ++e) {
                     float t = 0.f;
                     for (int q = 0; q < ppb; ++q) t += lds[(q * cgc + threadIdx.x) * 4 + e];
-                    atomicAdd(out + (long)img * c + threadIdx.x * 4 + e, t * scale);
+                    if (part) part[((long)img * gridDim.x + blockIdx.x) * c + threadIdx.x * 4 + e] = t * scale;
+                    else atomicAdd(out + (long)img * c + threadIdx.x * 4 + e, t * scale);
                 }
         } else if (active) {
-            for (int e = 0; e < 4; ++e) atomicAdd(out + (long)img * c + cg * 4 + e, acc[e] * scale);
+            for (int e = 0; e < 4; ++e) {
+                if (part) part[((long)img * gridDim.x + blockIdx.x) * c + cg * 4 + e] = acc[e] * scale;
+                else atomicAdd(out + (long)img * c + cg * 4 + e, acc[e] * scale);
+            }
         }
         __syncthreads();
     }
+    if (!part) return;
+    unsigned* tickets = (unsigned*)(part + (long)gridDim.y * gridDim.x * c);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_flag = atomicAdd(tickets + img, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    for (int ch = threadIdx.x; ch < c; ch += TPB) {
+        float t = 0.f;
+        for (unsigned k = 0; k < gridDim.x; ++k)
+            t += __hip_atomic_load(part + ((long)img * gridDim.x + k) * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[(long)img * c + ch] += t;
+    }
+    if (threadIdx.x == 0) tickets[img] = 0u;
 }
 
 // Effective-SE gate: u[n][co] = b[co] + sum_ci W[co][ci] * s[n][ci];  gate = relu6(u + 3) / 6
@@ -1016,19 +1039,33 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
     return PSSR_OK;
 }
 
-int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c, float scale, float* out,
-                           int dtype, pssr_stream_t s) {
+static int icd_chunks(int hw, int c) {
+    const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
+    int gx = (hw + ppb - 1) / ppb / 8;
+    return gx < 1 ? 1 : gx > 64 ? 64 : gx;
+}
+
+int64_t pssr_image_channel_dot_workspace_bytes(int n, int hw, int c) {
+    if (n <= 0 || hw <= 0 || c <= 0) return PSSR_ERR_ARG;
+    return ((int64_t)n * icd_chunks(hw, c) * c + n) * 4;
+}
+
+int pssr_image_channel_dot_ws(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c, float scale, float* out,
+                              int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t s) {
     PSSR_CHECK(a && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "image_channel_dot: bad args");
     CHECK_REF("image_channel_dot a", a_cs, a_co, c);
     if (b) CHECK_REF("image_channel_dot b", b_cs, b_co, c);
-    const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
-    int gx = (hw + ppb - 1) / ppb / 8;
-    if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
+    PSSR_CHECK(!workspace || workspace_bytes >= pssr_image_channel_dot_workspace_bytes(n, hw, c), PSSR_ERR_ARG, "image_channel_dot: workspace too small");
+    const int gx = icd_chunks(hw, c);
     DISPATCH_T(dtype, hipLaunchKernelGGL(image_channel_dot_kernel<T>, dim3(gx, n), dim3(TPB), 0, (hipStream_t)s, Ref{a, a_cs, a_co}, Ref{b, b_cs, b_co},
-                                         hw, c, scale, out));
+                                         hw, c, scale, out, (float*)workspace));
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
+}
+
+int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c, float scale, float* out,
+                           int dtype, pssr_stream_t s) {
+    return pssr_image_channel_dot_ws(a, a_cs, a_co, b, b_cs, b_co, n, hw, c, scale, out, dtype, nullptr, 0, s);
 }
 
 int pssr_ese_gate(const float* s_mean, const float* w_fc, const float* b_fc, int n, int c, float* u, float* gate, pssr_stream_t s) {

@@ -397,10 +397,25 @@ def layernorm2d_bwd(g, x, gamma, mean, rstd, dx, stats, n, h, w, c, dtype, g_cof
             "pssr_layernorm2d_bwd")
 
 
+_ICD_WS = {}
+
+
 def image_channel_dot(a, b, n, hw, c, scale, out, dtype, a_coff=0, b_coff=0):
+    """out[img][c] += scale * sum over the image's pixels of a * b, the same bits on every run (fixed-order partial sums through a
+    workspace kept per (device, size): the engines issue these calls on the launch stream only, so they are ordered, and the library
+    leaves its ticket words zero)."""
     bref = _ref(b, b_coff) if b is not None else (None, 0, 0)
-    L.check(L.lib().pssr_image_channel_dot(*_ref(a, a_coff), *bref, n, hw, c, C.c_float(scale), L.ptr(out), dtype, L.stream_ptr()),
-            "pssr_image_channel_dot")
+    lib = L.lib()
+    lib.pssr_image_channel_dot_workspace_bytes.restype = C.c_int64
+    need = lib.pssr_image_channel_dot_workspace_bytes(n, hw, c)
+    key = (out.device, need)
+    ws = _ICD_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(need, dtype=torch.uint8, device=out.device)
+        if not torch.cuda.is_current_stream_capturing():    # (a first use inside a capture gets a one-off buffer of the capture's pool)
+            _ICD_WS[key] = ws
+    L.check(lib.pssr_image_channel_dot_ws(*_ref(a, a_coff), *bref, n, hw, c, C.c_float(scale), L.ptr(out), dtype, L.ptr(ws), C.c_int64(need),
+                                          L.stream_ptr()), "pssr_image_channel_dot_ws")
 
 
 def ese_gate(s_mean, w_fc, b_fc, u, gate):
