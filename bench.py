@@ -38,6 +38,13 @@ class _Done(Exception):
     """Raised by the timing callback after the last timed step: callback exceptions abort the driver loop (as upstream)."""
 
 
+def whole_pass_roofline(tflops, scope):
+    """roofline object of an extra leg: the whole pass against the dense MFMA peak (the per-kernel breakdown of the inference pass is
+    profiles/r02_infer_*; its dominant kernels are the training forward's)."""
+    return {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "scope": scope}
+
+
 def pmc_traffic(mode):
     """HBM bytes per launch of the dominant kernel set from the committed rocprofv3 --pmc passes (profiles/traffic.json, written
     by tools/summarize_profile.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when absent."""
@@ -434,6 +441,8 @@ def main():
             res["infer"] = {"metric": f"HR tiles/sec ({hr_res}^2 4xSR) infer", "value": round(len(ids.val_idx) / t, 2), "unit": "HR tiles/s",
                             "config": f"predict_images over {len(ids.val_idx)} resident tiles, batch 128, uint8 predictions kept in HBM, {args.dtype}",
                             "algorithmic_tflops": round(len(ids.val_idx) / t * FWD_GFLOP_PER_TILE / 1e3, 2)}
+            res["infer"]["roofline"] = whole_pass_roofline(res["infer"]["algorithmic_tflops"], "predict_images pass: every kernel of the forward, "
+                                                           "uint8 clipping included; algorithmic FLOPs of the forward convolutions")
             del ids
             rng = np.random.default_rng(7)
             sheet = torch.from_numpy(rng.integers(0, 256, size=(1, 4096, 4096), dtype=np.uint8)).to(dev)
@@ -449,6 +458,9 @@ def main():
             res["sheet"] = {"metric": "HR tiles/sec (512^2 4xSR) whole-sheet inference", "value": round(sheet_tiles / min(ts[1:]), 2), "unit": "HR tiles/s",
                             "config": f"predict_sheet: 4096^2 uint8 sheet -> {sheet_tiles} tiles of 128^2 (overlap 32), batch 128, device tiling + "
                                       f"overlap-averaged reassembly, {args.dtype}", "seconds_per_sheet": round(min(ts[1:]), 4)}
+            res["sheet"]["algorithmic_tflops"] = round(sheet_tiles / min(ts[1:]) * FWD_GFLOP_PER_TILE / 1e3, 2)
+            res["sheet"]["roofline"] = whole_pass_roofline(res["sheet"]["algorithmic_tflops"], "predict_sheet: device tiling + forward + "
+                                                           "overlap-averaged reassembly, host wall clock; algorithmic FLOPs of the forward convolutions")
             del sheet
             model32 = make_model("f32")
             ds32 = DeviceTileDataset(tiles_dev[:512], hr_res=hr_res, lr_scale=4, crappifier=crap, val_split=0.1, rotation=True, device=dev, seed=5)
