@@ -82,9 +82,6 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     a.epi8 = esz == 2 && d->epilogue != PSSR_EPI_FINAL && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 &&
              (d->epilogue == PSSR_EPI_STORE || (d->aux_coff % 8 == 0 && d->aux_cstride % 8 == 0));
     if (!pssr_tunables().conv_epi8) a.epi8 = 0;
-    // the GELU-derivative epilogue with statistics (RDNet's 1x1 data gradients) takes the general epilogue: in the straight-line one
-    // the first statistic sum came out different in a few launches out of 40 (same outputs; tools/diag/det_gelu_stats.py), cause not found
-    if (d->epilogue == PSSR_EPI_DGRAD_GELU && (d->flags & PSSR_FLAG_STATS)) a.epi8 = 0;
     a.dbg = pssr_tunables().igemm_dbg;
     a.stamps = nullptr;
 #ifdef PSSR_V3_STAMPS

@@ -320,7 +320,16 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
                 float g[8];
                 X::unpack(packed, g);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (EPI == PSSR_EPI_STORE ? g[e] : a[e]); }
+                for (int e = 0; e < 8; ++e) {
+                    // GELU-derivative kind: the first sum is added with explicit v_add_f32.  hipcc packs these adds into
+                    // "v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]" (halves crossed) between the v_rcp / v_exp of the next channel
+                    // pair, and with that instruction the sum came out different by one workgroup's worth in a few launches out of 40
+                    // (outputs and second sum identical, tools/diag/det_gelu_stats.py, tests/test_gpu_determinism.py); the other
+                    // kinds have no transcendental instructions here and get an uncrossed v_pk_add_f32.
+                    if (EPI == PSSR_EPI_DGRAD_GELU) asm volatile("v_add_f32 %0, %0, %1" : "+v"(s1[e]) : "v"(g[e]));
+                    else s1[e] += g[e];
+                    s2[e] += g[e] * (EPI == PSSR_EPI_STORE ? g[e] : a[e]);
+                }
             }
             *(u32x4*)(outp + pix_index(gi, gy, gx, p.H, p.W, p.out_blk) * p.out_cs) = packed;
         }
