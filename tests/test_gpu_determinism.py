@@ -82,3 +82,41 @@ def test_image_channel_dot_identical_on_every_launch_and_right():
             assert torch.equal(out, first)
     ref = 0.5 * (a.double() * b.double()).sum(1)
     assert float((first.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_msssim_loss_and_gradient_identical_on_every_launch():
+    """MS-SSIM + L1 at the c2 loss shape (32 x 1 x 512 x 512): loss value and input gradient bit for bit on every evaluation."""
+    from pssr2_amd.util import SSIMLoss
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(32, 1, 512, 512, generator=g).cuda()
+    y = (x + 0.1 * torch.randn(32, 1, 512, 512, generator=g).cuda()).clamp(0, 1)
+    loss_fn = SSIMLoss(mix=0.8)
+    first = None
+    for _ in range(REPS):
+        xi = x.clone().requires_grad_(True)
+        loss = loss_fn(xi, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        cur = (loss.detach().clone(), xi.grad.clone())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])
+    assert torch.isfinite(first[0]) and float(first[1].abs().max()) > 0
+
+
+def test_fused_adamw_identical_on_every_run():
+    from pssr2_amd import ops
+    n = 1 << 22
+    g = torch.Generator().manual_seed(5)
+    p0, gr = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda() * 1e-2
+    first = None
+    for _ in range(REPS):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for step in (1, 2, 3):
+            ops.adamw_step(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+        torch.cuda.synchronize()
+        if first is None:
+            first = (p.clone(), m.clone(), v.clone())
+        else:
+            assert all(torch.equal(a, b) for a, b in zip((p, m, v), first))
