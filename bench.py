@@ -208,6 +208,27 @@ class StepClock:
             raise _Done()
 
 
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks as a CHILD ``torch.distributed.run`` (one process per
+    GPU, RCCL) before this process has made any HIP call -- counting devices does not initialise the GPU, and a process that has touched
+    the GPU must never re-launch itself -- pass rank 0's JSON line through, and return the launcher's exit code (non-zero when any rank
+    failed).  Fewer than N devices is an error, not a 1-GPU run: the line would otherwise claim ``n_gpus`` it never used."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("PSSR_BENCH_FORCE_DEVICE") is not None        # several gloo ranks on ONE card (tests / tools only)
+    have = torch.cuda.device_count()
+    if have < n and not rehearsal:
+        print(f"bench: --gpus {n} needs {n} devices, this node shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +248,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the infer / sheet / f32 legs that follow the headline region")
     ap.add_argument("--no-graph", action="store_true", help="PSSR_GRAPH=0: every kernel launched from Python by the drivers")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks")
     if args.no_graph:
         os.environ["PSSR_GRAPH"] = "0"
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -360,7 +360,7 @@ class DeviceTileDataset(Dataset):
         self.crappifier, self.rotation, self.transforms = crappifier, rotation, None
         self.extra_hr_files = None
         self.names = names if names is not None else [f"image{i}" for i in range(n)]
-        self._val_set = set(self.val_idx)
+        self._val_set, self._val_key = set(self.val_idx), None
         self.tile_counter = torch.zeros(1, dtype=torch.int64, device=self.images.device)
         self.gen = DevicePairGenerator(self.lr_scale, crappifier, seed=seed, tile_counter=self.tile_counter)
         self._item_bytes = 24             # struct pssr_gather_item {src, sh, sw, rot, flip_axis}
@@ -372,6 +372,11 @@ class DeviceTileDataset(Dataset):
         return self.names[idx]
 
     def _draw_rotation(self, idx):
+        # ``idx in self.val_idx`` as upstream (pssr/data.py:103), with the list hashed once per assignment / length change: users enlarge
+        # val_idx after training to predict every image
+        key = (id(self.val_idx), len(self.val_idx))
+        if key != self._val_key:
+            self._val_set, self._val_key = set(self.val_idx), key
         if self.rotation and idx not in self._val_set:
             return [bool(random.getrandbits(1)), random.choice((1, 2, (1, 2)))]      # the reference's draws, in its order
         return False
@@ -389,6 +394,8 @@ class DeviceTileDataset(Dataset):
             if rot:
                 axis = 3 if isinstance(rot[1], (tuple, list)) else int(rot[1])
             buf += struct.pack("<Qiiii", base + int(i) * stride, h, w, int(bool(rot and rot[0])), axis)
+        if not buf:                        # an empty order (val_split = 0, a rank without validation items): torch.frombuffer rejects b""
+            return torch.zeros(0, 3, dtype=torch.int64, device=self.images.device)
         return torch.frombuffer(buf, dtype=torch.int64).view(-1, 3).to(self.images.device)
 
     def device_batch(self, items):

@@ -99,3 +99,59 @@ def allreduce_mean_(tensors, group=None):
     for t in tensors:
         t.copy_(flat[o:o + t.numel()].view_as(t))
         o += t.numel()
+
+
+# --------------------------------------------------------------------------------------- rank failure
+class failure_watch:
+    """``with failure_watch():`` around a multi-rank driver loop: an exception on ONE rank ends ALL ranks, non-zero, within seconds.
+
+    The reference is single-process: a callback exception simply aborts the loop (pssr/napari/widgets.py:255-257).  With one
+    process per GPU the other ranks would sit in their next collective until its timeout (minutes).  Here the failing rank writes a key
+    into the process group's store before it re-raises; every rank runs a daemon thread that polls that key (and the store itself:
+    rank 0 hosts it, so a dead rank 0 shows as a connection error) and leaves with ``os._exit(3)`` -- the main thread may be blocked
+    inside a collective that will never complete, so nothing softer is reliable.  No-op when not distributed."""
+
+    _calls = 0
+    POLL_S = 0.25
+
+    def __init__(self, what="train_paired"):
+        self.what = what
+        self.active = is_distributed()
+
+    def __enter__(self):
+        if not self.active:
+            return self
+        import threading
+        failure_watch._calls += 1           # every rank enters the same drivers in the same order: same key on every rank
+        self.key = f"pssr2_amd/abort/{failure_watch._calls}"
+        self.store = dist.distributed_c10d._get_default_store()
+        self.rank = dist.get_rank()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._poll, name="pssr2-failure-watch", daemon=True)
+        self._thread.start()
+        return self
+
+    def _poll(self):
+        import sys
+        while not self._stop.wait(self.POLL_S):
+            try:
+                hit = self.store.check([self.key])
+            except Exception as e:          # the store is gone: the rank that hosted it died
+                hit, msg = True, f"store unreachable ({type(e).__name__})"
+            else:
+                msg = self.store.get(self.key).decode(errors="replace") if hit else ""
+            if hit and not self._stop.is_set():
+                print(f"[pssr2_amd] rank {self.rank}: leaving {self.what}: {msg}", file=sys.stderr, flush=True)
+                os._exit(3)
+
+    def __exit__(self, et, ev, tb):
+        if not self.active:
+            return False
+        self._stop.set()
+        if et is not None:
+            try:
+                self.store.set(self.key, f"rank {self.rank} raised {et.__name__}: {ev}")
+            except Exception:
+                pass
+        self._thread.join(2 * self.POLL_S + 1)
+        return False

@@ -255,6 +255,14 @@ class Engine:
             if ev is not None:
                 main.wait_event(ev)
 
+    def reset_backward_state(self):
+        """Forget a backward pass that did not run to its end (an aborted graph capture): no saved forward, no deferred side-stream
+        launch, no events of buffers the side stream was still reading."""
+        self.saved = None
+        self._deferred = None
+        self._pending = {}
+        self._side_on = False
+
     def _side_join(self):
         if self._side_on:
             self._flush_side()

@@ -32,7 +32,12 @@ def enabled():
 
 
 def supports(model, dataset, device):
-    """The replay path needs an engine-backed model on the GPU and a dataset that batches on the device."""
+    """The replay path needs an engine-backed model on the GPU and a dataset that batches on the device.  ``model.sync_bn`` with more
+    than one rank stays on the eager loop: its BatchNorm statistics are all-reduced in the middle of the forward and backward passes,
+    which a captured graph cannot hold with gloo (host-synchronising) and must not hold with RCCL (captured collectives would share
+    the communicator with the un-captured gradient all-reduce issued between the two replays: per-rank ordering is not guaranteed)."""
+    if getattr(model, "sync_bn", False) and D.rank_world()[1] > 1:
+        return False
     return (enabled() and getattr(model, "_engine", None) is not None and hasattr(dataset, "device_batch") and hasattr(dataset, "draw_items")
             and torch.device(device).type == "cuda" and getattr(dataset, "extra_hr_files", None) is None)
 
@@ -160,12 +165,20 @@ class TrainStepper:
         if self.graph is None:
             torch.cuda.synchronize()
             if self.split:
+                err = None
                 try:
                     self._capture_split()
                 except Exception as e:                          # any capture problem: one graph + one all-reduce after it
-                    if self.rank == 0:
-                        print(f"[pssr2_amd] split capture unavailable ({type(e).__name__}: {e}); all-reduce after the backward graph", flush=True)
+                    err = e
+                # every rank must issue the same collectives per step: the split is kept only if EVERY rank captured it
+                ok = torch.tensor([0.0 if err is not None else 1.0], device=self.engine._flat_grad.device)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                if float(ok) < 1.0:
+                    if self.rank == 0 or err is not None:
+                        why = f"{type(err).__name__}: {err}" if err is not None else "another rank could not capture it"
+                        print(f"[pssr2_amd] rank {self.rank}: split capture unavailable ({why}); all-reduce after the backward graph", flush=True)
                     self.split, self.graph, self.graph2 = False, None, None
+                    self.engine.reset_backward_state()          # an aborted capture may have left the side stream mid-backward
                     torch.cuda.synchronize()
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
@@ -256,7 +269,9 @@ class EvalStepper:
         self.clamp, self.image_range, self.to_u8 = clamp, image_range, to_u8
         self.engine = model._engine
         self.weights_move = weights_move           # True: the weights change between uses (validation inside training)
-        self.cur = _Cursor(dataset, batch_size, max(len(dataset.val_idx), batch_size), device)
+        # any order the drivers may ask for (validation split, a val_idx enlarged later to predict every image) fits a table of
+        # len(dataset) rows
+        self.cur = _Cursor(dataset, batch_size, max(len(dataset), len(dataset.val_idx), batch_size), device)
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.graph, self.outs, self.eager_done = None, None, 0
         self.sig = None

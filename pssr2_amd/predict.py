@@ -72,7 +72,9 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
         # one stepper (and one captured graph) per (dataset, batch size): a second call over the same dataset only replays
         cache = model._engine.__dict__.setdefault("_eval_steppers", {})
         evaler = cache.get((id(dataset), batch_size))
-        if evaler is None or evaler.dataset is not dataset:
+        if evaler is None or evaler.dataset is not dataset or len(idx) > evaler.cur.table.shape[0]:
+            if len(cache) >= 4:           # each stepper pins a captured graph and its memory pool: keep the most recent few
+                cache.pop(next(iter(cache)))
             evaler = cache[(id(dataset), batch_size)] = fastpath.EvalStepper(model, dataset, batch_size, device, to_u8=True, weights_move=False)
         dataloader = range(evaler.begin(idx))
     else:

@@ -87,64 +87,19 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
         evaler = fastpath.EvalStepper(model, dataset, batch_size, device, loss_fn=loss_fn, clamp=clamp, image_range=image_range)
 
     train_losses, val_losses = [], []
-    for epoch in range(epochs):
-        model.train()
-        if rank == 0:
-            print(f"Epoch {epoch}:")
-        if fast:
-            progress = tqdm(range(stepper.begin_epoch(list(train_sampler))), disable=rank != 0)
-        else:
-            progress = tqdm(train_dataloader, disable=rank != 0)
-        for batch_idx, data in enumerate(progress):
+    # world > 1: an exception on one rank (a callback's, say) ends every rank within seconds (pssr2_amd/distributed.py: failure_watch)
+    with D.failure_watch("train_paired"):
+        for epoch in range(epochs):
+            model.train()
+            if rank == 0:
+                print(f"Epoch {epoch}:")
             if fast:
-                hr, lr, hr_hat, loss = stepper.step()
+                progress = tqdm(range(stepper.begin_epoch(list(train_sampler))), disable=rank != 0)
             else:
-                if dataset.extra_hr_files is None:
-                    hr, lr = data
-                else:
-                    (hr, lr), extra = data
-                    extra = extra.to(device)
-                hr, lr = hr.to(device), lr.to(device)
-
-                hr_hat = model(lr)
-                if clamp:
-                    hr_hat = torch.clamp(hr_hat, 0, image_range)
-                loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
-                    else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
-                (scaler.scale(loss) if scaler is not None else loss).backward()
-                if world > 1 and engine is None:
-                    D.allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
-                if scaler is not None:
-                    scaler.step(optim, list(model.parameters()))
-                else:
-                    optim.step()
-                optim.zero_grad()
-
-            if batch_idx % log_frequency == 0 or batch_idx == len(progress) - 1:
-                train_losses.append(loss.item())
-                mse = nn.functional.mse_loss(hr_hat.detach() / image_range, hr / image_range)
-                if rank == 0 and hasattr(progress, "set_description"):
-                    progress.set_description(f"pixel[{pixel_metric(mse.item(), image_range):.2f}], psnr[{_psnr_metric(mse):.2f}], "
-                                             f"ssim[{_metric_ssim(hr_hat, hr, image_range):.3f}]")
-            if batch_idx == max(len(progress), 2) - 2:
-                last_full = [lr.cpu(), hr_hat.detach().cpu(), hr.cpu()]       # accessible from callbacks via locals
-            for idx, callback in enumerate(callbacks):
-                callback(locals()) if callback_locals[idx] else callback()
-        if fast:
-            stepper.finish()
-
-        model.eval()
-        if rank == 0:
-            print(f"Epoch {epoch} validation...")
-        val_loss = []
-        if fast:
-            progress = tqdm(range(evaler.begin(list(val_sampler))), disable=rank != 0)
-        else:
-            progress = tqdm(val_dataloader, disable=rank != 0)
-        with torch.no_grad():
+                progress = tqdm(train_dataloader, disable=rank != 0)
             for batch_idx, data in enumerate(progress):
                 if fast:
-                    hr, lr, hr_hat, loss, _ = evaler.step()
+                    hr, lr, hr_hat, loss = stepper.step()
                 else:
                     if dataset.extra_hr_files is None:
                         hr, lr = data
@@ -152,36 +107,83 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
                         (hr, lr), extra = data
                         extra = extra.to(device)
                     hr, lr = hr.to(device), lr.to(device)
+
                     hr_hat = model(lr)
                     if clamp:
                         hr_hat = torch.clamp(hr_hat, 0, image_range)
                     loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
                         else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
-                    val_loss.append(loss.detach().float().reshape(1))            # stays on device: one sync per epoch
-                if batch_idx == max(len(progress), 2) - 2:
-                    last_full_val = [lr.cpu(), hr_hat.cpu(), hr.cpu()]
-        if fast:
-            stat = evaler.mean_loss_stat()
-            engine.mark_weights_changed()
-        else:
-            stat = torch.stack([torch.cat(val_loss).sum(), torch.tensor(float(len(val_loss)), device=val_loss[0].device)]) \
-                if val_loss else torch.zeros(2, device=device)
-        if world > 1:
-            torch.distributed.all_reduce(stat)
-        val_loss = (stat[0] / stat[1].clamp(min=1)).item()
-        val_losses.append(val_loss)
-        if rank == 0:
-            print(f"Epoch {epoch} validation loss: {val_loss:4f}\n")
+                    (scaler.scale(loss) if scaler is not None else loss).backward()
+                    if world > 1 and engine is None:
+                        D.allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
+                    if scaler is not None:
+                        scaler.step(optim, list(model.parameters()))
+                    else:
+                        optim.step()
+                    optim.zero_grad()
 
-        if checkpoint_dir and epoch < epochs - 1 and rank == 0:
-            os.makedirs(checkpoint_dir, exist_ok=True)
-            torch.save(model.state_dict(), f"{checkpoint_dir}/checkpoint{epoch}_{model.__class__.__name__}_{val_loss:.4f}.pth")
-        if collage_dir and rank == 0:
-            os.makedirs(collage_dir, exist_ok=True)
-            _collage(*last_full_val, crop_res=dataset.crop_res, lr_scale=dataset.lr_scale).save(f"{collage_dir}/epoch{epoch}_loss{val_loss:.4f}.png")
-        if scheduler:
-            scheduler.step(val_loss) if include_metric else scheduler.step()
-            if hasattr(optim, "sync_device_lr"):
-                optim.sync_device_lr()
+                if batch_idx % log_frequency == 0 or batch_idx == len(progress) - 1:
+                    train_losses.append(loss.item())
+                    mse = nn.functional.mse_loss(hr_hat.detach() / image_range, hr / image_range)
+                    if rank == 0 and hasattr(progress, "set_description"):
+                        progress.set_description(f"pixel[{pixel_metric(mse.item(), image_range):.2f}], psnr[{_psnr_metric(mse):.2f}], "
+                                                 f"ssim[{_metric_ssim(hr_hat, hr, image_range):.3f}]")
+                if batch_idx == max(len(progress), 2) - 2:
+                    last_full = [lr.cpu(), hr_hat.detach().cpu(), hr.cpu()]       # accessible from callbacks via locals
+                for idx, callback in enumerate(callbacks):
+                    callback(locals()) if callback_locals[idx] else callback()
+            if fast:
+                stepper.finish()
+
+            model.eval()
+            if rank == 0:
+                print(f"Epoch {epoch} validation...")
+            val_loss = []
+            if fast:
+                progress = tqdm(range(evaler.begin(list(val_sampler))), disable=rank != 0)
+            else:
+                progress = tqdm(val_dataloader, disable=rank != 0)
+            with torch.no_grad():
+                for batch_idx, data in enumerate(progress):
+                    if fast:
+                        hr, lr, hr_hat, loss, _ = evaler.step()
+                    else:
+                        if dataset.extra_hr_files is None:
+                            hr, lr = data
+                        else:
+                            (hr, lr), extra = data
+                            extra = extra.to(device)
+                        hr, lr = hr.to(device), lr.to(device)
+                        hr_hat = model(lr)
+                        if clamp:
+                            hr_hat = torch.clamp(hr_hat, 0, image_range)
+                        loss = loss_fn(hr_hat / image_range, hr / image_range) if dataset.extra_hr_files is None \
+                            else loss_fn(hr_hat / image_range, hr / image_range, extra / image_range)
+                        val_loss.append(loss.detach().float().reshape(1))            # stays on device: one sync per epoch
+                    if batch_idx == max(len(progress), 2) - 2:
+                        last_full_val = [lr.cpu(), hr_hat.cpu(), hr.cpu()]
+            if fast:
+                stat = evaler.mean_loss_stat()
+                engine.mark_weights_changed()
+            else:
+                stat = torch.stack([torch.cat(val_loss).sum(), torch.tensor(float(len(val_loss)), device=val_loss[0].device)]) \
+                    if val_loss else torch.zeros(2, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(stat)
+            val_loss = (stat[0] / stat[1].clamp(min=1)).item()
+            val_losses.append(val_loss)
+            if rank == 0:
+                print(f"Epoch {epoch} validation loss: {val_loss:4f}\n")
+
+            if checkpoint_dir and epoch < epochs - 1 and rank == 0:
+                os.makedirs(checkpoint_dir, exist_ok=True)
+                torch.save(model.state_dict(), f"{checkpoint_dir}/checkpoint{epoch}_{model.__class__.__name__}_{val_loss:.4f}.pth")
+            if collage_dir and rank == 0:
+                os.makedirs(collage_dir, exist_ok=True)
+                _collage(*last_full_val, crop_res=dataset.crop_res, lr_scale=dataset.lr_scale).save(f"{collage_dir}/epoch{epoch}_loss{val_loss:.4f}.png")
+            if scheduler:
+                scheduler.step(val_loss) if include_metric else scheduler.step()
+                if hasattr(optim, "sync_device_lr"):
+                    optim.sync_device_lr()
 
     return train_losses, val_losses

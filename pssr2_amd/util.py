@@ -149,7 +149,7 @@ class SSIMLoss(nn.Module):
 
     def forward_divided(self, input, target, divisor: float):
         """``self(input / divisor, target / divisor)`` -- what pssr/train.py:101 computes with divisor 255 -- without the two quotient
-        tensors and the gradient's division pass: the training kernels divide on load (IEEE division, same values)."""
+        tensors and the gradient's division pass: the training kernels scale on load (a rounded multiplication by the f32 reciprocal 1/in_div, which is how torch divides a device tensor by a scalar: same values)."""
         if input.shape != target.shape:
             raise ValueError(f"Input images should have the same dimensions, but got {input.shape} and {target.shape}.")
         cfg = (self.win, float(self.mix), bool(self.ms), self.K[0], self.K[1], 1.0, self.weights)

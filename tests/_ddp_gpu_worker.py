@@ -127,12 +127,61 @@ def fastpath(rank, world):
     assert torch.equal(vs[0], vs[1])          # the validation loss is averaged over ranks
 
 
+def syncbn_fast(rank, world):
+    """sync_bn + a device-resident dataset + two ranks: train_paired must leave the hipGraph path (its BatchNorm all-reduces cannot be
+    captured) and still train, ranks identical."""
+    import torch.distributed as dist
+    from pssr2_amd import fastpath as FP
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    from test_gpu_fastpath import _tiles
+    model = _model(5)
+    model.sync_bn = True
+    ds = DeviceTileDataset(_tiles(40, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.1, rotation=True, device="cuda",
+                           seed=4 + rank)
+    assert not FP.supports(model, ds, "cuda")
+    FP.LAST_TRAIN_STEPPER = None
+    opt = FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3)
+    tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 1, device="cuda", log_frequency=1)
+    assert FP.LAST_TRAIN_STEPPER is None and len(tl) > 0 and all(np.isfinite(tl)) and all(np.isfinite(vl))
+    cs = torch.tensor([float(sum(p.detach().double().abs().sum() for p in model.parameters()))], dtype=torch.float64).cuda()
+    both = [torch.zeros_like(cs) for _ in range(world)]
+    dist.all_gather(both, cs)
+    assert float(both[0]) == float(both[1]), "ranks diverged"
+
+
+def failure(rank, world):
+    """A callback raises on rank 1 in the middle of an epoch: every rank must leave, non-zero, within seconds."""
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    from test_gpu_fastpath import _tiles
+    model = _model(3)
+    ds = DeviceTileDataset(_tiles(88, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.1, rotation=True, device="cuda",
+                           seed=21 + rank)
+    opt = FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3)
+    seen = [0]
+
+    def cb():
+        seen[0] += 1
+        if rank == 1 and seen[0] == 4:
+            raise RuntimeError("callback failed on rank 1")
+    train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 50, device="cuda", log_frequency=2, callbacks=[cb])
+    raise AssertionError("train_paired returned although a rank had failed")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     from pssr2_amd import distributed as D
-    torch.cuda.set_device(0)
-    rank, world, _ = D.init_from_env(backend="gloo")
-    {"reducer": reducer, "syncbn": syncbn, "fastpath": fastpath}[mode](rank, world)
+    backend = os.environ.get("PSSR_TEST_BACKEND", "gloo")          # "nccl" (= RCCL) needs one device per rank
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    rank, world, _ = D.init_from_env(backend=backend)
+    {"reducer": reducer, "syncbn": syncbn, "fastpath": fastpath, "syncbn_fast": syncbn_fast, "failure": failure}[mode](rank, world)
     torch.cuda.synchronize()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -60,3 +60,64 @@ def test_two_rank_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _failing_worker(rank, world, port):
+    """Rank 1 raises inside a failure_watch; rank 0 is parked in a collective that can never complete."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from pssr2_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    with D.failure_watch("test loop"):
+        dist.barrier()
+        if rank == 1:
+            raise RuntimeError("callback failed on rank 1")
+        t = torch.zeros(4)
+        dist.all_reduce(t)            # rank 1 never joins: without the watch this waits for gloo's timeout (30 min)
+        dist.all_reduce(t)
+
+
+def test_exception_on_one_rank_ends_all_ranks():
+    """an exception on one rank tears down every rank (non-zero exit) within seconds."""
+    import time
+    ctx = mp.get_context("spawn")
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+    took = time.time() - t0
+    alive = [p.is_alive() for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert not any(alive), f"a rank was still running after {took:.0f} s"
+    assert all(p.exitcode not in (0, None) for p in procs), [p.exitcode for p in procs]
+
+
+def test_failure_watch_is_silent_without_failure():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_quiet_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _quiet_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from pssr2_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    for _ in range(2):                     # two drivers in a row: a fresh key each time
+        with D.failure_watch("quiet loop"):
+            t = torch.ones(2)
+            dist.all_reduce(t)
+            assert float(t[0]) == 2.0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)

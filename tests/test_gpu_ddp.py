@@ -1,4 +1,4 @@
-"""Data-parallel path on real kernels: 2 gloo ranks sharing the one card of the test box (tests/_ddp_gpu_worker.py).  On an 8-GPU node the
+"""Data-parallel path on real kernels: 2 GLOO ranks sharing the one card of the test box (tests/_ddp_gpu_worker.py).  On an 8-GPU node the
 same code runs one rank per GPU over RCCL; what is checked here is everything but the transport: that an asynchronous bucket
 all-reduce launched from inside the backward pass never reads a gradient the side-stream weight-gradient kernels have not finished,
 that sync_bn reproduces whole-batch BatchNorm, and that train_paired's two-graph replay keeps the ranks identical."""
@@ -12,14 +12,22 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(mode, timeout=240):
-    port = 29700 + os.getpid() % 200 + {"reducer": 0, "syncbn": 1, "fastpath": 2}[mode]
+MODES = ["reducer", "syncbn", "fastpath", "syncbn_fast", "failure"]
+
+
+def _spawn(mode, backend="gloo"):
+    port = 29700 + os.getpid() % 200 + MODES.index(mode) + (10 if backend == "nccl" else 0)
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank) if backend == "nccl" else "0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", PSSR_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_ddp_gpu_worker.py"), mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
+    return procs
+
+
+def _run(mode, timeout=240, backend="gloo"):
+    procs = _spawn(mode, backend)
     outs = []
     try:
         for p in procs:
@@ -42,3 +50,38 @@ def test_sync_bn_equals_whole_batch():
 
 def test_train_paired_two_rank_split_graph():
     _run("fastpath")
+
+
+def test_sync_bn_with_device_dataset_takes_the_eager_loop():
+    _run("syncbn_fast")
+
+
+def test_callback_exception_on_one_rank_ends_all_ranks():
+    import time
+    procs = _spawn("failure")
+    t0 = time.time()
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=180)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode not in (0, None) for p in procs), [(p.returncode, o[-800:]) for p, o in zip(procs, outs)]
+    assert "callback failed on rank 1" in outs[1]
+    assert "leaving train_paired" in outs[0], outs[0][-800:]
+    assert time.time() - t0 < 170
+
+
+def _two_devices():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_devices(), reason="RCCL needs one device per rank: this box has fewer than 2 (duplicate-GPU ranks are refused by RCCL)")
+@pytest.mark.parametrize("mode", ["reducer", "syncbn", "fastpath"])
+def test_rccl_two_devices(mode):
+    """The same three checks over the ``nccl`` backend (= RCCL over xGMI), one rank per device.  Skipped on the 1-GPU test boxes; the
+    8-GPU node of the scaling run is where this transport first executes."""
+    _run(mode, backend="nccl")

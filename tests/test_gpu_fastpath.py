@@ -158,3 +158,29 @@ def test_predict_images_graph_equals_eager():
     assert any(not np.array_equal(ref2[k], ref[k]) for k in ref)
     for k in ref2:
         assert np.array_equal(got2[k], ref2[k]), k
+
+
+def test_empty_validation_split_and_enlarged_val_idx():
+    """(a) a DeviceTileDataset without validation items (val_split=0) trains through the graph path -- the empty gather
+    table used to raise in torch.frombuffer after the first epoch; (b) predict_images on a dataset whose val_idx the user enlarged
+    after a first call ("predict every image") gets a new gather table instead of 'epoch longer than the captured gather table'."""
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.predict import predict_images
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    torch.manual_seed(2)
+    model = ResUNet(hidden=[16, 32], depth=1).cuda()
+    model.compute_dtype = torch.float32
+    ds = DeviceTileDataset(_tiles(32, 64, seed=9), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(5, 0, 0), val_split=0, rotation=True, device="cuda")
+    assert ds.val_idx == [] and ds.draw_items([]).shape == (0, 3)
+    tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), FusedAdamW(model.parameters(), lr=1e-3), 2, device="cuda", log_frequency=1)
+    assert len(tl) == 8 and all(np.isfinite(tl)) and vl == [0.0, 0.0]        # the reference's DataLoader path reports 0 for an empty split too
+    ds.val_idx = [0, 1, 2]
+    a = predict_images(model, ds, device="cuda", batch_size=2, out_dir=None)
+    assert len(a) == 3
+    ds.val_idx = list(range(len(ds)))
+    b = predict_images(model, ds, device="cuda", batch_size=2, out_dir=None)
+    assert len(b) == 32 and all(np.array_equal(a[k], b[k]) for k in a)
