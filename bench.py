@@ -412,7 +412,8 @@ def main():
             "metric": f"HR tiles/sec ({hr_res}^2 4xSR) {args.mode}",
             "value": round(tiles_per_s, 2), "unit": "HR tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / steps_done, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype if args.mode == "train" else {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "f32"}[model._engine.storage_dtype(False)],
+            "data": "synthetic",
             "config": {"workload": f"{name} {args.channels}-ch 4xSR {args.lr_res}^2->{hr_res}^2 {args.mode}, batch {args.batch}/GPU, "
                                    f"{n_tiles if n_tiles else 'one 4096^2 sheet:'} {'synthetic-EM uint8 HR tiles resident in HBM' if n_tiles else ''}, "
                                    f"{'AdditiveGaussian(13)' if args.crappifier == 'gaussian' else 'Poisson()'} device crappifier, MS-SSIM+L1 (mix .8), FusedAdamW",
@@ -462,11 +463,14 @@ def main():
     # ---- extra legs (rank 0 of a 1-GPU run): inference, sheet, exact-f32 training, CPU oracle
     if rank == 0 and world == 1 and args.mode == "train" and not args.no_extras and args.model == "resunet" and args.channels == 1:
         try:
+            infer_dt = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "f32"}[model._engine.storage_dtype(False)]
             ids = DeviceTileDataset(tiles_dev, hr_res=hr_res, lr_scale=4, crappifier=crap, val_split=1.0, rotation=False, device=dev, seed=99)
             ids.device_outputs = True
             t = run_infer(model, ids, 128)
             res["infer"] = {"metric": f"HR tiles/sec ({hr_res}^2 4xSR) infer", "value": round(len(ids.val_idx) / t, 2), "unit": "HR tiles/s",
-                            "config": f"predict_images over {len(ids.val_idx)} resident tiles, batch 128, uint8 predictions kept in HBM, {args.dtype}",
+                            "dtype": infer_dt,
+                            "config": f"predict_images over {len(ids.val_idx)} resident tiles, batch 128, uint8 predictions kept in HBM, {infer_dt} storage "
+                                      f"(the default inference storage of a {args.dtype} model: Engine.storage_dtype)",
                             "algorithmic_tflops": round(len(ids.val_idx) / t * FWD_GFLOP_PER_TILE / 1e3, 2)}
             res["infer"]["roofline"] = whole_pass_roofline(res["infer"]["algorithmic_tflops"], "predict_images pass: every kernel of the forward, "
                                                            "uint8 clipping included; algorithmic FLOPs of the forward convolutions")
@@ -484,7 +488,7 @@ def main():
                 ts.append(time.perf_counter() - t0)
             res["sheet"] = {"metric": "HR tiles/sec (512^2 4xSR) whole-sheet inference", "value": round(sheet_tiles / min(ts[1:]), 2), "unit": "HR tiles/s",
                             "config": f"predict_sheet: 4096^2 uint8 sheet -> {sheet_tiles} tiles of 128^2 (overlap 32), batch 128, device tiling + "
-                                      f"overlap-averaged reassembly, {args.dtype}", "seconds_per_sheet": round(min(ts[1:]), 4)}
+                                      f"overlap-averaged reassembly, {infer_dt} storage", "dtype": infer_dt, "seconds_per_sheet": round(min(ts[1:]), 4)}
             res["sheet"]["algorithmic_tflops"] = round(sheet_tiles / min(ts[1:]) * FWD_GFLOP_PER_TILE / 1e3, 2)
             res["sheet"]["roofline"] = whole_pass_roofline(res["sheet"]["algorithmic_tflops"], "predict_sheet: device tiling + forward + "
                                                            "overlap-averaged reassembly, host wall clock; algorithmic FLOPs of the forward convolutions")

@@ -143,15 +143,14 @@ int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
 /* bytes of `workspace` with which pssr_conv2d would split K for this shape (0: no split); negative = PSSR_ERR_*.  Pointers
  * in `desc` are ignored. */
 int64_t pssr_conv2d_workspace_bytes(const pssr_conv_desc* desc);
-/* Tuning / test knob: which main loop pssr_conv2d uses for images >= 16x16.  0 (default): always the 128-pixel tiles; 1:
- * the pipelined 256-pixel LDS-DMA loop when the grid fills the chip; 2: the pipelined loop whenever the shape allows.
- * Returns the previous mode (any other argument only queries).  Also settable with the environment variable PSSR_IGEMM_V2. */
+/* Deprecated (ABI version 1): selected the round-1 pipelined 256-pixel loop, which conv_v3_kernel replaced (tunable IGEMM_V3
+ * below).  Kept so that old bindings load; ignores its argument and returns 0. */
 int pssr_conv2d_pipeline_mode(int mode);
 
 /* Kernel-selection tunables (no reference counterpart: the reference has no native code).  ONE process-wide table, filled once
  * from the environment variables PSSR_<NAME> on first use and changed afterwards only through pssr_set_option(); no launch
  * path reads the environment.  Names: IGEMM_V3 (1: LDS-DMA / counted-wait 3x3 loop for 16-bit layers with > 64 output
- * channels on >= 16x16 images when its 256-pixel tiles fill the chip; 2: whenever the shape allows; 0: the 128-pixel loop), IGEMM_V2, IGEMM_FLAT, IGEMM_BIG, IGEMM_KSPLIT, CONV_EPI8, WGRAD_LEAN,
+ * channels on >= 16x16 images when its 256-pixel tiles fill the chip; 2: whenever the shape allows; 0: the 128-pixel loop), IGEMM_FLAT, IGEMM_BIG, IGEMM_KSPLIT, CONV_EPI8, WGRAD_LEAN,
  * WGRAD_BLOCKS, WGRAD_BLOCKS_1X1, DWCONV_TILE, DWWG_BLOCKS.  pssr_set_option returns the previous value (>= 0) or PSSR_ERR_ARG
  * for an unknown name / out-of-range value; pssr_get_option returns the value or PSSR_ERR_ARG. */
 int pssr_set_option(const char* name, int value);

@@ -27,7 +27,6 @@ struct Entry { const char* name; int PssrTunables::*field; int dflt; int lo, hi;
 const Entry kEntries[] = {
     {"IGEMM_FLAT", &PssrTunables::igemm_flat, 1, 0, 1},
     {"IGEMM_BIG", &PssrTunables::igemm_big, 1, 0, 2},
-    {"IGEMM_V2", &PssrTunables::igemm_v2, 0, 0, 2},
     {"IGEMM_V3", &PssrTunables::igemm_v3, 1, 0, 2},
     {"IGEMM_V3_64", &PssrTunables::igemm_v3_64, 1, 0, 1},
     {"IGEMM_DBG", &PssrTunables::igemm_dbg, 0, 0, 255},

@@ -4,11 +4,11 @@
 
 using pssr_conv::ConvArgs;
 
-// kept for ABI version 1 callers: pssr_set_option("IGEMM_V2", mode)
+// ABI version 1 entry, kept so that old bindings still load: the round-1 pipelined loop it selected is gone (superseded by
+// conv_v3_kernel, tunable IGEMM_V3); always reports mode 0 and changes nothing
 extern "C" int pssr_conv2d_pipeline_mode(int mode) {
-    const int old = pssr_tunables().igemm_v2;
-    if (mode >= 0 && mode <= 2) pssr_tunables().igemm_v2 = mode;
-    return old;
+    (void)mode;
+    return 0;
 }
 
 static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* query_ws);

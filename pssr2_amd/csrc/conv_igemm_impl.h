@@ -806,293 +806,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC <= 4 ? 3
     conv_epilogue_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
 }
 
-// =================================================================================================================
-// Pipelined main loop ("v2") for layers that fill the chip with 256-pixel tiles: 16x16 output pixels x BN channels per
-// workgroup, 4 waves as WM x WN, each wave (256/WM) pixels x (BN/WN) channels = MI x NJ accumulator tiles (MI*NJ = 8).
-//   * the weight slices of the NEXT stage go global -> LDS by LDS-DMA (global_load_lds_dwordx4; the packed weight
-//     layout IS the LDS image), double-buffered, while the current stage is multiplied: no staging registers, no
-//     ds_write, one barrier per stage;
-//   * 3x3: a stage = one kernel row (3 taps) of one 32-byte channel chunk; the halo tile of a chunk is staged once
-//     (registers: BatchNorm+ReLU / GELU prologue, zero padding) and serves its 3 stages; it is requested at the first
-//     stage of the previous chunk and committed at its last, so the loads have 3 stages to land;
-//   * 1x1: a stage = 2 channel chunks, each with its own 256-pixel image;
-//   * LDS 45-48 KB and <= 256 registers: two workgroups per CU overlap each other's epilogue and pipeline fill.
-template <int BN, int TAPS> struct Cfg2 {
-    static constexpr int TWL = 4, THL = 4, TW = 16, TH = 16, NI = 1, MPIX = 256;
-    static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = HPI;
-    static constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
-    static constexpr int MI = MPIX / 32 / WM, NJ = BN / (32 * WN);
-    static constexpr int NSL = TAPS == 9 ? 9 : 2;                                  // weight slices per stage (3x3: a whole chunk)
-    static constexpr int A_PIX = TAPS == 9 ? HP : MPIX;                             // pixels of one staged image
-    static constexpr int A_IMGS = TAPS == 9 ? 1 : NSL;                              // images per stage buffer
-    static constexpr int A_BYTES = A_IMGS * A_PIX * 32, B_BYTES = NSL * BN * 32;
-    static constexpr int A_ITEMS = (2 * A_IMGS * A_PIX + 255) / 256;
-    static constexpr int B_PIECES = B_BYTES / 1024;                                 // 1-KiB LDS-DMA wave-instructions per stage
-    static constexpr int E_BYTES = WM * 32 * BN * 4, RED_BYTES = 4 * BN * 2 * 4;
-    static constexpr int RING = 2;                                                  // weight stages resident in LDS
-    static constexpr int MAIN_BYTES = 2 * A_BYTES + RING * B_BYTES;
-    static constexpr int LDS_BYTES = (MAIN_BYTES > E_BYTES + RED_BYTES) ? MAIN_BYTES : (E_BYTES + RED_BYTES);
-    static constexpr int PERM = 0;
-};
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
-
-template <typename T, int BN, int TAPS0>
-__global__ __launch_bounds__(256, 1) void conv_igemm2_kernel(const ConvArgs p) {
-    using C = Cfg2<BN, TAPS0>;
-    using X = TT<T>;
-    constexpr int EPS = X::EPS, KCH = X::KCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Abuf = smem;                               // [2][A_BYTES]
-    char* Bbuf = smem + 2 * C::A_BYTES;              // [RING][B_BYTES]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int h = lane >> 5, r = lane & 31;
-    const int bid = blockIdx.x;
-    const int tn = bid % p.tiles_n;
-    int tmi = bid / p.tiles_n;
-    const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
-    const int tile_y = tmi % p.tiles_y;
-    const int img0 = tmi / p.tiles_y;
-    const int x0 = tile_x << C::TWL, y0 = tile_y << C::THL, n0 = tn * BN;
-
-    // ---- staging descriptors of the input image(s)
-    long a_pix[C::A_ITEMS], a_pix1[C::A_ITEMS];
-    int a_lds[C::A_ITEMS], a_half[C::A_ITEMS], a_sub[C::A_ITEMS];
-    bool a_ok[C::A_ITEMS];
-#pragma unroll
-    for (int it = 0; it < C::A_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        const int half = idx & 1;
-        int pp = idx >> 1;
-        const int sub = (TAPS0 == 9) ? 0 : pp / C::A_PIX;      // 1x1: which chunk image of the stage
-        pp -= sub * C::A_PIX;
-        int gy, gx;
-        if constexpr (TAPS0 == 9) { gy = y0 + pp / C::HW2 - 1; gx = x0 + pp % C::HW2 - 1; }
-        else { gy = y0 + (pp >> C::TWL); gx = x0 + (pp & (C::TW - 1)); }
-        const bool in_range = idx < 2 * C::A_IMGS * C::A_PIX;
-        const bool inb = in_range && img0 < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_ok[it] = inb;
-        a_pix[it] = inb ? pix_index(img0, gy, gx, p.H, p.W, p.in0_blk) : 0;
-        a_pix1[it] = inb ? ((long)img0 * p.H + gy) * p.W + gx : 0;
-        a_lds[it] = in_range ? (sub * C::A_PIX * 32 + pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
-        a_half[it] = half;
-        a_sub[it] = sub;
-    }
-    int a_p0[C::MI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-        const int m = wm * C::MI * 32 + mi * 32 + r;
-        const int tx = m & (C::TW - 1), ty = m >> C::TWL;
-        a_p0[mi] = (TAPS0 == 9) ? ty * C::HW2 + tx : m;
-    }
-    int b_off[C::NJ];
-#pragma unroll
-    for (int nj = 0; nj < C::NJ; ++nj) {
-        const int n = wn * C::NJ * 32 + nj * 32 + r;
-        b_off[nj] = n * 32 + ((h ^ ((n >> 3) & 1)) << 4);
-    }
-    f32x16 acc[C::MI][C::NJ];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < C::NJ; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
-
-    const int n0c = p.nchunks[0], n1c = p.nchunks[1];
-    // stage -> (source, first chunk, first tap, slices).  3x3: 3 stages per source-0 chunk, then one 1-slice stage per
-    // source-1 chunk (centre tap of the same halo geometry).  1x1: NSL chunks per stage, single source.
-    const int nst = (TAPS0 == 9) ? n0c + n1c : (n0c + C::NSL - 1) / C::NSL;
-    u32x4 a_reg[C::A_ITEMS];
-
-#define V2_ISSUE_A(SRC, CHUNK)                                                                                    \
-    {                                                                                                             \
-        const T* in_ = (const T*)p.in[SRC];                                                                       \
-        const int cs_ = p.in_cs[SRC];                                                                             \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            int ch_ = (CHUNK) + a_sub[it];                                                                        \
-            if (TAPS0 != 9 && ch_ >= n0c) ch_ = n0c - 1;       /* odd chunk count: the last slice is not multiplied */ \
-            a_reg[it] = *(const u32x4*)(in_ + ((SRC) ? a_pix1[it] : a_pix[it]) * cs_ + p.in_co[SRC] + ch_ * KCH + a_half[it] * EPS); \
-        }                                                                                                         \
-    }
-#define V2_COMMIT_A(SRC, CHUNK, DST)                                                                              \
-    {                                                                                                             \
-        const bool pro_ = ((SRC) == 0) && (p.prologue == PSSR_PRO_BN_RELU);                                       \
-        const bool gelu_ = ((SRC) == 0) && (p.prologue == PSSR_PRO_GELU);                                         \
-        _Pragma("unroll") for (int it = 0; it < C::A_ITEMS; ++it) {                                               \
-            if (a_lds[it] >= 0) {                                                                                 \
-                u32x4 v = a_reg[it];                                                                              \
-                if (!a_ok[it]) v = u32x4{0u, 0u, 0u, 0u};                                                         \
-                if (pro_ && a_ok[it]) {                                                                           \
-                    int ch_ = (CHUNK) + a_sub[it];                                                                \
-                    if (TAPS0 != 9 && ch_ >= n0c) ch_ = n0c - 1;                                                  \
-                    const int c0 = ch_ * KCH + a_half[it] * EPS;                                                  \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; e += 4) {                                          \
-                        const float4 sc = *(const float4*)(p.pro_scale + c0 + e);                                 \
-                        const float4 sh = *(const float4*)(p.pro_shift + c0 + e);                                 \
-                        f[e + 0] = fmaxf(fmaf(f[e + 0], sc.x, sh.x), 0.f);                                        \
-                        f[e + 1] = fmaxf(fmaf(f[e + 1], sc.y, sh.y), 0.f);                                        \
-                        f[e + 2] = fmaxf(fmaf(f[e + 2], sc.z, sh.z), 0.f);                                        \
-                        f[e + 3] = fmaxf(fmaf(f[e + 3], sc.w, sh.w), 0.f);                                        \
-                    }                                                                                             \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                if (gelu_) {                                                                                      \
-                    float f[EPS];                                                                                 \
-                    X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
-                    v = X::pack(f);                                                                               \
-                }                                                                                                 \
-                *(u32x4*)((DST) + a_lds[it]) = v;                                                                 \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // weight slices of stage S -> Bbuf[S & 1] by LDS-DMA: piece q = 1 KiB = 64 lanes x 16 B, linear in LDS and in the packed weights
-#define V2_ISSUE_B(S)                                                                                             \
-    {                                                                                                             \
-        const int s_ = (S);                                                                                       \
-        const bool src1_ = (TAPS0 == 9) && s_ >= n0c;                                                             \
-        const int chunk_ = (TAPS0 == 9) ? (src1_ ? s_ - n0c : s_) : s_ * C::NSL;                                  \
-        const int tap0_ = 0;                                                                                      \
-        const int taps_ = (TAPS0 == 9 && !src1_) ? 9 : 1;                                                         \
-        const char* wsrc_ = (const char*)p.w[src1_ ? 1 : 0];                                                      \
-        char* bdst_ = Bbuf + (s_ % C::RING) * C::B_BYTES;                                                         \
-        nb_issued = 0;                                                                                            \
-        constexpr int PPS_ = BN * 32 / 1024;                  /* pieces per slice */                              \
-        _Pragma("unroll") for (int j = 0; j < (C::B_PIECES + 3) / 4; ++j) {                                       \
-            const int q = wave + 4 * j;                                                                           \
-            const int sl = q / PPS_, pq = q % PPS_;                                                               \
-            int ck = chunk_, tp = tap0_;                                                                          \
-            if (TAPS0 == 9) tp += sl; else ck += sl;                                                              \
-            const bool live = q < C::B_PIECES && (TAPS0 == 9 ? (!src1_ || sl == 0) : ck < n0c);                   \
-            if (live) {                                                                                           \
-                const char* g_ = wsrc_ + (((long)ck * taps_ + tp) * p.n_pad + n0) * 32 + pq * 1024 + lane * 16;    \
-                __builtin_amdgcn_global_load_lds((glb_void_t*)g_, (lds_void_t*)(bdst_ + sl * BN * 32 + pq * 1024), 16, 0, 0); \
-                ++nb_issued;                                                                                      \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // one stage = NSLICES weight slices against the staged image.  The fragments of slice i+1 are requested before the MFMAs
-    // of slice i are issued (two register sets, compile-time indices after unrolling), so a wave that is alone on its SIMD
-    // keeps the LDS latency under its own matrix work.
-#define V2_FRAGS(SET, SL, AIMG, KY3, KX0)                                                                         \
-    {                                                                                                             \
-        _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) {                                                    \
-            int pa;                                                                                               \
-            if (TAPS0 == 9) pa = a_p0[mi] + ((KY3) ? ((SL) / 3) : 1) * C::HW2 + ((KY3) ? ((SL) % 3) : (KX0));     \
-            else pa = (SL) * C::A_PIX + a_p0[mi];                                                                 \
-            const int pin = (TAPS0 == 9) ? pa : a_p0[mi];                                                         \
-            af[SET][mi] = *(const u32x4*)((AIMG) + pa * 32 + ((h ^ ((pin >> 3) & 1)) << 4));                      \
-        }                                                                                                         \
-        _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) bf[SET][nj] = *(const u32x4*)(bs_ + (SL) * BN * 32 + b_off[nj]); \
-    }
-#define V2_COMPUTE(BSTAGE, AIMG, KY3, NSLICES, KX0)                                                               \
-    {                                                                                                             \
-        const char* bs_ = Bbuf + (BSTAGE) * C::B_BYTES;                                                           \
-        u32x4 af[2][C::MI], bf[2][C::NJ];                                                                         \
-        V2_FRAGS(0, 0, AIMG, KY3, KX0)                                                                            \
-        _Pragma("unroll") for (int sl = 0; sl < (NSLICES); ++sl) {                                                \
-            if (sl + 1 < (NSLICES)) V2_FRAGS((sl + 1) & 1, sl + 1, AIMG, KY3, KX0)                                \
-            _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi)                                                  \
-                _Pragma("unroll") for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[sl & 1][mi], bf[sl & 1][nj]); \
-            /* pin the interleave: one fragment read of the NEXT slice behind each MFMA of this one (left alone, the  \
-               scheduler minimises registers and serialises read -> wait -> 2 MFMAs) */                             \
-            if (sl + 1 < (NSLICES)) {                                                                             \
-                _Pragma("unroll") for (int q = 0; q < C::MI + C::NJ; ++q) {                                       \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-                }                                                                                                 \
-                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ - (C::MI + C::NJ), 0);                  \
-            } else {                                                                                              \
-                __builtin_amdgcn_sched_group_barrier(0x008, C::MI * C::NJ, 0);                                    \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-
-    int abuf = 0;
-    int nb_issued = 0;          // LDS-DMA instructions this wave issued for the youngest weight stage
-    // wait until only this wave's youngest `n` vector-memory operations (= its DMAs of the stage after next) are in flight
-#define V2_WAIT_BUT(N)                                                                                            \
-    { const int n_ = (N);                                                                                         \
-      if (n_ >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                               \
-      else if (n_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
-      else if (n_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                          \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    if constexpr (TAPS0 == 9) {
-        // stage = one 32-byte channel chunk of source 0 (9 taps) or one chunk of the 1x1 source 1 (centre tap of its halo
-        // image); weights and image of stage s+1 are requested at the start of stage s (LDS-DMA / registers) and must have
-        // landed at its end: one wait + one barrier per stage
-        const int nimg = n0c + n1c;
-        if (n0c > 0) { V2_ISSUE_A(0, 0) } else { V2_ISSUE_A(1, 0) }
-        V2_ISSUE_B(0)
-        if (n0c > 0) { V2_COMMIT_A(0, 0, Abuf) } else { V2_COMMIT_A(1, 0, Abuf) }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int c = 0; c < nimg; ++c) {
-            const bool more = c + 1 < nimg;
-            const int nsrc = (c + 1 >= n0c) ? 1 : 0, nchunk = nsrc ? c + 1 - n0c : c + 1;
-            if (more) {
-                if (nsrc) V2_ISSUE_A(1, nchunk) else V2_ISSUE_A(0, nchunk)
-                V2_ISSUE_B(c + 1)
-            }
-            if (c < n0c) V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 1, 9, 0)
-            else V2_COMPUTE(c & 1, Abuf + abuf * C::A_BYTES, 0, 1, 1)
-            if (more) {
-                if (nsrc) V2_COMMIT_A(1, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES) else V2_COMMIT_A(0, nchunk, Abuf + (abuf ^ 1) * C::A_BYTES)
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            abuf ^= 1;
-        }
-    } else {
-        V2_ISSUE_B(0)
-        V2_ISSUE_A(0, 0)
-        V2_COMMIT_A(0, 0, Abuf)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int s = 0; s < nst; ++s) {
-            const bool more = s + 1 < nst;
-            if (more) { V2_ISSUE_B(s + 1) V2_ISSUE_A(0, (s + 1) * C::NSL) }
-            if (s * C::NSL + 1 < n0c) V2_COMPUTE(s & 1, Abuf + (s & 1) * C::A_BYTES, 0, 2, 0)
-            else V2_COMPUTE(s & 1, Abuf + (s & 1) * C::A_BYTES, 0, 1, 0)
-            if (more) V2_COMMIT_A(0, (s + 1) * C::NSL, Abuf + ((s + 1) & 1) * C::A_BYTES)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-#undef V2_WAIT_BUT
-#undef V2_FRAGS
-#undef V2_ISSUE_A
-#undef V2_COMMIT_A
-#undef V2_ISSUE_B
-#undef V2_COMPUTE
-    __syncthreads();
-    conv_epilogue_any<T, BN, C>(p, acc, smem, tid, x0, y0, img0, n0);
-}
-
-template <typename T, int BN, int TAPS0>
-int launch2_t(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg2<BN, TAPS0>;
-    ConvArgs p = a;
-    p.tiles_x = cdiv(a.W, C::TW);
-    p.tiles_y = cdiv(a.H, C::TH);
-    p.tiles_n = cdiv(a.cout, BN);
-    const long blocks = (long)p.tiles_x * p.tiles_y * a.N * p.tiles_n;
-    PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<T, BN, TAPS0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, BN, TAPS0>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
 
 }  // namespace
 #include "conv_v3.h"
@@ -1181,22 +896,6 @@ bool use_v3(const ConvArgs& a) {
     // 128-pixel loop (twice the workgroups) measured faster (32^2 x 256 and 16^2 x 512 layers at batch 32: 828 vs 757, 713 vs 643 TFLOP/s)
     const long blocks = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.N * cdiv(a.cout, BN);
     return blocks >= 384;
-}
-
-// the pipelined kernel needs >= 16x16 images and enough 256-pixel tiles to fill the chip (PSSR_IGEMM_V2=0 disables it)
-// 0 (default): off; 1: for 3x3 layers whose 256-pixel tiles fill the chip twice over; 2: whenever the shape allows (tests).
-// Round-1 measurement: correct (tests/test_gpu_conv.py runs every case with mode 2) but slower than the 128-pixel
-// main loop, because hipcc serialises each fragment ds_read behind an lgkmcnt(0) at this register pressure
-// (128 accumulators + descriptors at 1-2 waves per SIMD); it needs hand-placed fragment reads before it pays.
-
-template <typename T, int BN>
-bool use_v2(const ConvArgs& a) {
-    const int g_v2_mode = pssr_tunables().igemm_v2;
-    if (!g_v2_mode || a.W < 16 || a.H < 16 || a.ksplit < 0) return false;      // (ksplit < 0: workspace-size query)
-    if (a.taps[0] == 1 && a.nchunks[1] != 0) return false;
-    if (g_v2_mode == 2) return true;
-    const long blocks = (long)cdiv(a.W, 16) * cdiv(a.H, 16) * a.N * cdiv(a.cout, BN);
-    return a.taps[0] == 9 && blocks >= 512;
 }
 
 // workgroups a split-K launch aims for (PSSR_IGEMM_KSPLIT overrides)
@@ -1301,7 +1000,6 @@ template <typename T>
 int launch_bn(const ConvArgs& a, hipStream_t s) {
     if (a.cout > 64) {
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 128>(a)) return launch3_t<T, 128>(a, s); }
-        if (use_v2<T, 128>(a)) return a.taps[0] == 9 ? launch2_t<T, 128, 9>(a, s) : launch2_t<T, 128, 1>(a, s);
         if constexpr (sizeof(T) == 2) {
             if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
         }
@@ -1309,7 +1007,6 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
     }
     if (a.cout > 32) {
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 64>(a)) return launch3_t<T, 64>(a, s); }
-        if (use_v2<T, 64>(a)) return a.taps[0] == 9 ? launch2_t<T, 64, 9>(a, s) : launch2_t<T, 64, 1>(a, s);
         return launch_geo<T, 64>(a, s);
     }
     return launch_geo<T, 32>(a, s);

@@ -19,7 +19,7 @@
 //     free (the 18-pixel pitch of the old [pixel][32 B] image made the two image rows of a fragment collide);
 //   * the multiply of a stage is one inline-asm block: fragment reads of tap t+1 are issued between the MFMAs of
 //     tap t (two register sets), one `lgkmcnt(0)` per tap.  Left to hipcc this loop was serialised behind full waits
-//     (conv_igemm2_kernel, round 1);
+//     (the round-1 pipelined loop, since removed);
 //   * 57.6 KB of LDS and <= 256 registers: two workgroups per CU, each covering the other's barriers and epilogue.
 //
 // Row permutation: ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32).  MFMA row r of a

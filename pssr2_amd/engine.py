@@ -312,21 +312,38 @@ class Engine:
         self._convs = {}
         self._built_for = device
 
-    def _repack_all(self):
-        """Re-pack every cached conv weight whose parameter changed (an optimizer step changes all of them) with ONE
-        launch instead of one per (conv, form).  Entries that were never packed yet stay on the lazy path of _Conv.get."""
+    def storage_dtype(self, train):
+        """Storage type of a pass.  Training: ``model.compute_dtype``.  Inference (eval-mode forward): ``model.infer_dtype`` when set,
+        else float16 for a bfloat16 model, else ``compute_dtype``.  bf16 keeps 8 significant bits of every stored activation and
+        weight; over the ~50 layers of a ResUNet that adds up to 0.5-2e-3 dB of PSNR against the f32 path -- AT the 1e-3 dB parity
+        criterion, not inside it.  fp16 storage (11 bits, the same MFMA rate, the same bytes) measures
+        1-3e-4 dB; its narrower range is no issue for a forward pass through BatchNorm'ed activations (gradients are what need bf16's
+        range or loss scaling).  A network whose activations overflow fp16 (max 65504) shows as inf / nan outputs: set
+        ``model.infer_dtype = torch.bfloat16`` for it (tests/test_gpu_parity_trained.py)."""
+        m = self.model
+        if train:
+            return m.compute_dtype
+        inf = getattr(m, "infer_dtype", None)
+        if inf is not None:
+            return inf
+        return torch.float16 if m.compute_dtype == torch.bfloat16 else m.compute_dtype
+
+    def _repack_all(self, code=None):
+        """Re-pack every cached conv weight (of storage type ``code``) whose parameter changed -- an optimizer step changes all of them
+        -- with ONE launch instead of one per (conv, form).  Entries that were never packed yet stay on the lazy path of _Conv.get;
+        copies in another storage type (the fp16 copies of a bf16-trained model's validation passes) wait for a pass that uses them."""
         convs = [c for c in self._convs.values() if c.packed]
-        stale = [(c, key) for c in convs for key in c.packed if c.version.get(key) != c.ver()]
+        stale = [(c, key) for c in convs for key in c.packed if (code is None or key[1] == code) and c.version.get(key) != c.ver()]
         if len(stale) < 8:
             return
         sig = tuple((id(c), key, c.m.weight.data_ptr(), c.packed[key].data.data_ptr()) for c, key in stale)
-        if getattr(self, "_pack_sig", None) != sig:
+        cache = self.__dict__.setdefault("_pack_tables", {})
+        if cache.get(code, (None, None))[0] != sig:
             import ctypes as C
             arr = (L.PackItem * len(stale))(*[c.item(*key) for c, key in stale])
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self._pack_table = host.to(stale[0][0].m.weight.device)
-            self._pack_sig = sig
-        L.check(L.lib().pssr_pack_conv_weight_batch(L.ptr(self._pack_table), len(stale), L.stream_ptr()), "pssr_pack_conv_weight_batch")
+            cache[code] = (sig, host.to(stale[0][0].m.weight.device))
+        L.check(L.lib().pssr_pack_conv_weight_batch(L.ptr(cache[code][1]), len(stale), L.stream_ptr()), "pssr_pack_conv_weight_batch")
         for c, key in stale:
             c.version[key] = c.ver()
 
@@ -561,11 +578,11 @@ class Engine:
         n, c, h, w = x.shape
         if c != self.cin:
             raise ValueError(f"expected {self.cin} input channels, got {c}")
-        dt = m.compute_dtype
+        dt = self.storage_dtype(train)
         code = ops.dtype_code(dt)
         self._check_supported(code, h, w, train)
         p = self._plan(n, h, w, dt, x.device)
-        self._repack_all()
+        self._repack_all(code)
         Lv, hid = self.L, self.hidden
         if train:
             p.f64.buf.zero_()

@@ -122,7 +122,9 @@ class ResUNet(nn.Module):
         ``encoder_pool`` (PSP pooling): SURVEY.md §8f-4.
 
         Extra attribute: ``compute_dtype``: torch.float32 (exact-f32 MFMA, default), torch.bfloat16 or torch.float16
-        (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16).
+        (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16); ``infer_dtype``: storage type of
+        eval-mode forwards (default None: float16 for a bfloat16 model -- 3 more mantissa bits at the same rate keep inference within
+        1e-3 dB of the f32 path -- else ``compute_dtype``).
         """
         super().__init__()
         channels = _force_list(channels)
@@ -153,6 +155,7 @@ class ResUNet(nn.Module):
 
         self.channels, self.hidden, self.depth = channels, hidden, depth
         self.compute_dtype = torch.float32
+        self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
         self._engine = Engine(self)
 
     def forward(self, x):
@@ -334,6 +337,7 @@ class RDResUNet(nn.Module):
         self.skips = skips
         self.channels, self.hidden, self.depth = channels, hidden, depth
         self.compute_dtype = torch.float32
+        self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
         from .rd_engine import RDEngine
         self._engine = RDEngine(self)
 

@@ -337,11 +337,11 @@ class RDEngine(Engine):
         n, c, h, w = x.shape
         if c != self.cin:
             raise ValueError(f"expected {self.cin} input channels, got {c}")
-        dt = m.compute_dtype
+        dt = self.storage_dtype(train)
         code = ops.dtype_code(dt)
         self._check_supported_rd(code, h, w, train)
         p = self._plan(n, h, w, dt, x.device)
-        self._repack_all()
+        self._repack_all(code)
         hid, nd = self.hidden, len(self.hidden)
         if train:
             p.f64.buf.zero_()

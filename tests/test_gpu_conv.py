@@ -31,17 +31,13 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[(0, 2), (2, 0), (0, 0)], ids=["v3", "pipelined", "legacy"])
+@pytest.fixture(params=[2, 0], ids=["v3", "legacy"])
 def pipeline_mode(request):
-    """Run a test with the LDS-DMA v3 loop wherever the shape allows, with the round-1 pipelined
-    256-pixel loop forced on, and with both off (the 128-pixel loop everywhere)."""
+    """Run a test with the LDS-DMA v3 loop wherever the shape allows and with it off (the 128-pixel loop everywhere)."""
     from pssr2_amd import _lib as L
-    v2, v3 = request.param
-    old2 = L.lib().pssr_set_option(b"IGEMM_V2", v2)
-    old3 = L.lib().pssr_set_option(b"IGEMM_V3", v3)
-    assert old2 >= 0 and old3 >= 0
+    old3 = L.lib().pssr_set_option(b"IGEMM_V3", request.param)
+    assert old3 >= 0
     yield request.param
-    L.lib().pssr_set_option(b"IGEMM_V2", old2)
     L.lib().pssr_set_option(b"IGEMM_V3", old3)
 
 

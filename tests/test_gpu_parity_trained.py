@@ -4,7 +4,8 @@ A default ResUNet is trained here (bf16, through train_paired's replayed graph) 
 well past bilinear quality, then the SAME weights and the SAME noisy LR tiles go through
   * the CPU oracle (torch fp32 restatement of pssr/models/resunet.py:65-96, pinned by the reference fixtures),
   * the exact-f32 HIP path,
-  * the bf16 and fp16 storage paths (what bench.py times),
+  * the model's default inference path (fp16 storage for a bf16-trained model: what predict_images and bench.py's infer legs
+    run) and the bf16 storage path forced for inference,
 and the per-tile PSNR against the HR ground truth (data range 255, as pssr/train.py:105-109 logs it) is compared.  The measured
 differences are printed; the asserted bounds are the measured values with a margin (DESIGN.md §2 quotes them)."""
 import math
@@ -24,7 +25,14 @@ def _psnr(y, hr):
     return (10 * torch.log10(255.0 ** 2 / mse)).cpu().numpy()
 
 
+SEEDS = (0, 1, 2)
+
+
 def test_trained_weights_psnr_f32_bf16_fp16_vs_oracle(capsys):
+    """Three trainings (seeds 0-2).  Asserted, per training and per tile: f32-HIP vs the CPU oracle <= 1e-4 dB; the DEFAULT inference
+    path of the bf16-trained model -- what predict_images / bench.py's infer legs run: fp16 storage, Engine.storage_dtype -- vs f32
+    <= 1e-3 dB (the north-star criterion; measured 1-3e-4).  bf16 storage forced for inference (model.infer_dtype = bfloat16) is
+    measured and printed: 0.5-2e-3 dB, AT the criterion, which is why it is not the default."""
     sys.path.insert(0, ROOT)
     from oracle import model_ref
     from pssr2_amd.crappifiers import AdditiveGaussian
@@ -36,49 +44,63 @@ def test_trained_weights_psnr_f32_bf16_fp16_vs_oracle(capsys):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(16) as ex:                      # numpy releases the GIL in the FFTs / RNG fills
         tiles = np.stack(list(ex.map(lambda i: synthetic_em_tile(50000 + i, 512, 1), range(768))))
-    torch.manual_seed(0)
-    model = ResUNet().cuda()
-    model.compute_dtype = torch.bfloat16
-    ds = DeviceTileDataset(tiles, hr_res=512, lr_scale=4, crappifier=AdditiveGaussian(13, 0, 0), val_split=0.05, rotation=True, device="cuda", seed=3)
-    opt = FusedAdamW(model.parameters(), lr=1e-3)
-    with capsys.disabled():
-        tl, vl = train_paired(model, ds, 32, SSIMLoss(mix=0.8), opt, epochs=int(os.environ.get("PSSR_PARITY_EPOCHS", "40")), device="cuda", log_frequency=1000)
-    # ---- fixed evaluation batch: 8 validation tiles, one noisy reduction
-    rows = ds.draw_items(ds.val_idx[:8])
-    hr, lr = ds.device_batch(rows)
-    hr, lr = hr.clone(), lr.clone()
-    model.eval()
-    out = {}
-    with torch.no_grad():
-        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("fp16", torch.float16)):
-            model.compute_dtype = dt
-            out[name] = model(lr).float().clone()
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    tiles_dev = torch.from_numpy(tiles).cuda()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    with torch.no_grad():
-        y_ref, _ = model_ref.resunet_forward(lr[:4].cpu(), sd, 5, 3, 4, train=False)
-    p = {k: _psnr(v, hr) for k, v in out.items()}
-    p_ref = _psnr(y_ref.cuda(), hr[:4])
-    # bilinear-quality yardstick: nearest-neighbour blow-up of the noisy LR tile
-    p_nn = _psnr(torch.nn.functional.interpolate(lr, scale_factor=4, mode="bilinear", align_corners=False), hr)
-    d_f32_ref = np.abs(p["f32"][:4] - p_ref).max()
-    d_bf16 = np.abs(p["bf16"] - p["f32"]).max()
-    d_fp16 = np.abs(p["fp16"] - p["f32"]).max()
-    u8 = {k: v.clamp(0, 255).to(torch.uint8) for k, v in out.items()}
-    frac_bf16 = float((u8["bf16"] != u8["f32"]).float().mean())
-    max_bf16 = int((u8["bf16"].int() - u8["f32"].int()).abs().max())
-    frac_fp16 = float((u8["fp16"] != u8["f32"]).float().mean())
+    worst = {"f32_ref": 0.0, "default": 0.0, "bf16": 0.0, "fp16": 0.0}
+    for seed in SEEDS:
+        torch.manual_seed(seed)
+        model = ResUNet().cuda()
+        model.compute_dtype = torch.bfloat16
+        ds = DeviceTileDataset(tiles_dev, hr_res=512, lr_scale=4, crappifier=AdditiveGaussian(13, 0, 0), val_split=0.05, rotation=True, device="cuda",
+                               seed=3 + seed)
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        with capsys.disabled():
+            tl, vl = train_paired(model, ds, 32, SSIMLoss(mix=0.8), opt, epochs=int(os.environ.get("PSSR_PARITY_EPOCHS", "40")), device="cuda",
+                                  log_frequency=1000)
+        # ---- fixed evaluation batch: 8 validation tiles, one noisy reduction
+        rows = ds.draw_items(ds.val_idx[:8])
+        hr, lr = ds.device_batch(rows)
+        hr, lr = hr.clone(), lr.clone()
+        model.eval()
+        assert model._engine.storage_dtype(False) == torch.float16 and model._engine.storage_dtype(True) == torch.bfloat16
+        out = {}
+        with torch.no_grad():
+            out["default"] = model(lr).float().clone()          # bf16-trained model, default inference storage
+            for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("fp16", torch.float16)):
+                model.infer_dtype = dt
+                out[name] = model(lr).float().clone()
+            model.infer_dtype = None
+        assert torch.equal(out["default"], out["fp16"])
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            y_ref, _ = model_ref.resunet_forward(lr[:4].cpu(), sd, 5, 3, 4, train=False)
+        p = {k: _psnr(v, hr) for k, v in out.items()}
+        p_ref = _psnr(y_ref.cuda(), hr[:4])
+        # bilinear-quality yardstick: bilinear blow-up of the noisy LR tile
+        p_nn = _psnr(torch.nn.functional.interpolate(lr, scale_factor=4, mode="bilinear", align_corners=False), hr)
+        d = {"f32_ref": np.abs(p["f32"][:4] - p_ref).max(), "default": np.abs(p["default"] - p["f32"]).max(),
+             "bf16": np.abs(p["bf16"] - p["f32"]).max(), "fp16": np.abs(p["fp16"] - p["f32"]).max()}
+        u8 = {k: v.clamp(0, 255).to(torch.uint8) for k, v in out.items()}
+        frac = {k: float((u8[k] != u8["f32"]).float().mean()) for k in ("bf16", "fp16")}
+        lsb = {k: int((u8[k].int() - u8["f32"].int()).abs().max()) for k in ("bf16", "fp16")}
+        with capsys.disabled():
+            print(f"\n[trained parity, seed {seed}] val loss {vl[0]:.4f} -> {vl[-1]:.4f}; PSNR per tile: f32 {np.round(p['f32'], 3)} "
+                  f"(bilinear blow-up {np.round(p_nn, 2)})")
+            print(f"[trained parity, seed {seed}] max |PSNR_f32-HIP - PSNR_oracle| = {d['f32_ref']:.2e} dB   (criterion 1e-3)")
+            print(f"[trained parity, seed {seed}] max |PSNR - PSNR_f32|: default inference storage (fp16) {d['default']:.2e} dB; bf16 storage forced "
+                  f"{d['bf16']:.2e} dB")
+            print(f"[trained parity, seed {seed}] uint8 outputs vs f32: bf16 differs in {100 * frac['bf16']:.2f} % of pixels (max {lsb['bf16']} LSB), "
+                  f"fp16 in {100 * frac['fp16']:.2f} % (max {lsb['fp16']} LSB)")
+        # 24.2 dB is where this data saturates: the HR tiles carry white noise of sigma 8 that no model can predict (ceiling 30.1 dB)
+        # on top of what a 4x reduction + N(0, 13) noise destroys; the bilinear blow-up of the same LR tiles sits at 22.7 dB
+        assert p["f32"].min() >= 24.0 and (p["f32"] - p_nn).min() > 1.0, "the net did not train past bilinear quality"
+        assert torch.isfinite(out["default"]).all()
+        assert d["f32_ref"] <= 1e-4               # north-star criterion 1e-3 dB; measured 1-8e-8
+        assert d["default"] <= 1e-3               # the north-star criterion for the path the drivers run; measured 1-3e-4
+        assert d["bf16"] <= 5e-3                  # informational bound: bf16 inference storage sits AT the criterion (0.5-2.1e-3)
+        assert lsb["bf16"] <= 1 and lsb["fp16"] <= 1
+        for k in worst:
+            worst[k] = max(worst[k], float(d[k]))
+        del model, ds, opt
     with capsys.disabled():
-        print(f"\n[trained parity] val loss {vl[0]:.4f} -> {vl[-1]:.4f}; PSNR per tile: f32 {np.round(p['f32'], 3)} (bilinear blow-up {np.round(p_nn, 2)})")
-        print(f"[trained parity] max |PSNR_f32-HIP - PSNR_oracle| = {d_f32_ref:.2e} dB   (criterion 1e-3)")
-        print(f"[trained parity] max |PSNR_bf16 - PSNR_f32| = {d_bf16:.2e} dB;  max |PSNR_fp16 - PSNR_f32| = {d_fp16:.2e} dB")
-        print(f"[trained parity] PSNR of the bf16 / fp16 output against the f32 output: {_psnr(out['bf16'], out['f32']).min():.1f} / {_psnr(out['fp16'], out['f32']).min():.1f} dB")
-        print(f"[trained parity] uint8 outputs: bf16 differs from f32 in {100 * frac_bf16:.2f} % of pixels (max {max_bf16} LSB), fp16 in {100 * frac_fp16:.2f} %")
-    # 24.2 dB is where this data saturates: the HR tiles carry white noise of sigma 8 that no model can predict (ceiling 30.1 dB)
-    # on top of what a 4x reduction + N(0, 13) noise destroys; the bilinear blow-up of the same LR tiles sits at 22.7 dB
-    assert p["f32"].min() >= 24.0 and (p["f32"] - p_nn).min() > 1.0, "the net did not train past bilinear quality"
-    assert d_f32_ref <= 1e-4                  # north-star criterion 1e-3 dB; measured 2e-8
-    assert d_fp16 <= 1e-3                     # measured 2.0e-4
-    assert d_bf16 <= 5e-3                     # measured 0.5e-3 .. 2.1e-3 over ten trainings (the weights differ run to run: statistics and
-                                              # under-filled weight gradients are summed with atomics): bf16 storage sits AT the 1e-3 criterion, not inside it
-    assert max_bf16 <= 1                      # uint8 predictions: 5.7 % of the pixels move, each by one grey level (truncation, pssr/predict.py:245)
+        print(f"[trained parity] worst over seeds {SEEDS}: " + ", ".join(f"{k} {v:.2e} dB" for k, v in worst.items()))
