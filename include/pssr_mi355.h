@@ -340,6 +340,11 @@ int pssr_crappify_gaussian(const float* in, float* out, int tiles, int64_t per_t
 int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_tile, float intensity,
                           float gain, float spread, uint64_t seed, uint64_t tile_offset, int flags,
                           const uint64_t* tile_counter, pssr_stream_t stream);
+/* The same mix with the Poisson samples handed in (f64 [n], e.g. numpy's legacy-stream draws of the reference run): numpy's
+ * arithmetic of pssr/crappifiers.py:81-86 exactly (x*(1-i) in float32, y*i and the sums in float64), then flags (pssr/data.py:487).
+ * For exact-parity tests, like `noise` of pssr_crappify_gaussian; `intensity` / `gain` are the Python floats, undrawn. */
+int pssr_crappify_poisson_samples(const float* in, const double* samples, float* out, int64_t n, double intensity,
+                                  double gain, int flags, pssr_stream_t stream);
 /* `tile_counter` (device, may be NULL) is added to tile_offset inside the kernel, so a captured hipGraph
  * draws fresh noise on every replay; pssr_counter_add advances it on the stream. */
 int pssr_counter_add(uint64_t* counter, uint64_t inc, pssr_stream_t stream);
@@ -530,6 +535,16 @@ int pssr_patch_tiles_u8(const uint8_t* tiles, uint8_t* sheet, int c, int n_rows,
 int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image);
 int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat, uint8_t* hr_norm, uint8_t* hr_hat_norm, int n_images,
                             int64_t pixels_per_image, float pmin, float pmax, void* workspace, pssr_stream_t stream);
+/* The same for a prediction [n_images][h][w] whose size differs from the ground truth's [n_images][H][W] (pssr/util.py:176-179): the
+ * covariance amplitude is taken between the ground truth and skimage.transform.resize(prediction, (H, W)) -- order-1 interpolation at
+ * (i + 0.5) * in / out - 0.5, mirror boundary, Gaussian pre-filter sigma = (in / out - 1) / 2 along shrinking axes (scikit-image
+ * >= 0.19, i.e. scipy.ndimage.zoom(grid_mode=True) + gaussian_filter; restated and checked against scipy in oracle/metrics_ref.py;
+ * scikit-image itself is absent: parity unpinned).  Outputs keep their own sizes, as upstream.  Workspace of
+ * pssr_normalize_preds_resized_workspace_bytes(...) bytes. */
+int64_t pssr_normalize_preds_resized_workspace_bytes(int n_images, int H, int W, int h, int w);
+int pssr_normalize_preds_resized_u8(const uint8_t* hr, int H, int W, const uint8_t* hr_hat, int h, int w, uint8_t* hr_norm,
+                                    uint8_t* hr_hat_norm, int n_images, float pmin, float pmax, void* workspace,
+                                    pssr_stream_t stream);
 
 /* Per-image restoration metrics of uint8 image pairs [n_images][h][w] resident in HBM, as pssr/predict.py:193-203 computes them
  * through skimage.metrics (peak_signal_noise_ratio, structural_similarity with data_range 255: uniform 7x7 window, K1 .01,

@@ -172,6 +172,19 @@ __global__ void poisson_noise_kernel(const float* __restrict__ in, float* __rest
     }
 }
 
+// Poisson with the samples handed in (exact-parity tests: the reference draws them from numpy's frozen legacy stream).  The arithmetic
+// is numpy's for pssr/crappifiers.py:81-86: `x * (1 - intensity)` stays float32 (a Python float is a weak scalar), `y * intensity`
+// is int64 * float -> float64, their sum and `+ gain` are float64; then np.round / clip as flags say (pssr/data.py:487).
+__global__ void poisson_samples_kernel(const float* __restrict__ in, const double* __restrict__ samples, float* __restrict__ out, long n,
+                                       double intensity, double gain, int flags) {
+    const float keep = (float)(1.0 - intensity);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float t1 = __fmul_rn(in[i], keep);
+        const double v = __dadd_rn(__dadd_rn((double)t1, __dmul_rn(samples[i], intensity)), gain);
+        out[i] = (float)finish(v, flags);
+    }
+}
+
 // separable Gaussian, edge replicate, truncate 4 sigma; f64 accumulate, f32 between the passes (scipy.ndimage)
 __global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, float sigma, int axis,
                                  float gain, int flags) {
@@ -314,6 +327,14 @@ int pssr_crappify_poisson(const float* in, float* out, int tiles, int64_t per_ti
     PSSR_CHECK(in && out && tiles > 0 && per_tile > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_poisson: bad args");
     hipLaunchKernelGGL(poisson_noise_kernel, dim3(grid1d((long)tiles * per_tile)), dim3(256), 0, (hipStream_t)s, in, out, tiles, (long)per_tile,
                        intensity, gain, spread, seed, tile_offset, flags, tile_counter);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_crappify_poisson_samples(const float* in, const double* samples, float* out, int64_t n, double intensity, double gain, int flags,
+                                  pssr_stream_t s) {
+    PSSR_CHECK(in && samples && out && n > 0 && flags >= 0 && flags <= 3, PSSR_ERR_ARG, "crappify_poisson_samples: bad args");
+    hipLaunchKernelGGL(poisson_samples_kernel, dim3(grid1d((long)n)), dim3(256), 0, (hipStream_t)s, in, samples, out, (long)n, intensity, gain, flags);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -106,9 +106,13 @@ __device__ float percentile_f32(const int* cum /* inclusive cumulative histogram
     return __fadd_rn(a, __fmul_rn(d, t));
 }
 
+// `n_hat` != n (a prediction of another size, pssr/util.py:176-179): the covariance of the RESIZED prediction with the ground truth
+// arrives as per-workgroup partial sums [sum r, sum r * hr] of resize_cov_sums_kernel (`cov_part`, `n_part` pairs per image); every
+// other quantity of the prediction (mean, variance, the rescaling mean) runs over its own n_hat pixels.
 __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __restrict__ hr_all, const uint8_t* __restrict__ hat_all,
-                                                             uint8_t* __restrict__ out_hr_all, uint8_t* __restrict__ out_hat_all, int n,
-                                                             float pmin, float pmax, char* __restrict__ ws_all, long ws_per_image) {
+                                                             uint8_t* __restrict__ out_hr_all, uint8_t* __restrict__ out_hat_all, int n, int n_hat,
+                                                             float pmin, float pmax, char* __restrict__ ws_all, long ws_per_image,
+                                                             const double* __restrict__ cov_part, int n_part) {
     __shared__ int hist[256], hist2[256], cum[256];
     __shared__ float hn[256], hn2[256], a_tab[256], hat2[256];
     __shared__ double b_tab[256];
@@ -117,19 +121,26 @@ __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __re
     __shared__ float bc;
     __shared__ int n_leaves_s;
     const uint8_t* hr = hr_all + (long)blockIdx.x * n;
-    const uint8_t* hat = hat_all + (long)blockIdx.x * n;
+    const uint8_t* hat = hat_all + (long)blockIdx.x * n_hat;
+    const int n_big = n > n_hat ? n : n_hat;
     Leaf* leaves = (Leaf*)(ws_all + (long)blockIdx.x * ws_per_image);
-    float* sums = (float*)(leaves + (n / 32 + 16));
+    Leaf* leaves_h = leaves + (n_big / 32 + 16);                       // leaves of an n_hat-element reduction (== leaves when n_hat == n)
+    float* sums = (float*)(leaves_h + (n_big / 32 + 16));
+    __shared__ int n_leaves_h_s;
     const int tid = threadIdx.x;
     hist[tid] = 0; hist2[tid] = 0;
     if (tid == 0) {
         int c = 0;
         for (int c0 = 0; c0 < n; c0 += NPY_BUF) build_leaves(c0, n - c0 < NPY_BUF ? n - c0 : NPY_BUF, leaves, c);
         n_leaves_s = c;
+        c = 0;
+        for (int c0 = 0; c0 < n_hat; c0 += NPY_BUF) build_leaves(c0, n_hat - c0 < NPY_BUF ? n_hat - c0 : NPY_BUF, leaves_h, c);
+        n_leaves_h_s = c;
     }
     __syncthreads();
-    const int n_leaves = n_leaves_s;
-    for (int i = tid; i < n; i += NT) { atomicAdd(&hist[hr[i]], 1); atomicAdd(&hist2[hat[i]], 1); }
+    const int n_leaves = n_leaves_s, n_leaves_h = n_leaves_h_s;
+    for (int i = tid; i < n; i += NT) atomicAdd(&hist[hr[i]], 1);
+    for (int i = tid; i < n_hat; i += NT) atomicAdd(&hist2[hat[i]], 1);
     __syncthreads();
     if (tid == 0) { int c = 0; for (int v = 0; v < 256; ++v) { c += hist[v]; cum[v] = c; } }
     __syncthreads();
@@ -142,22 +153,36 @@ __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __re
     __syncthreads();
     const float mean_hn = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return hn[hr[i]]; }, &bc), (float)n);
     hn2[tid] = __fsub_rn(hn[tid], mean_hn);
-    const float mean_hat = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return (float)hat[i]; }, &bc), (float)n);
+    const float mean_hat = __fdiv_rn(pairwise_f32(n_hat, leaves_h, n_leaves_h, sums, [&](int i) { return (float)hat[i]; }, &bc), (float)n_hat);
     hat2[tid] = __fsub_rn((float)tid, mean_hat);
     __syncthreads();
     int vmin = 0;
     while (hist[vmin] == 0) ++vmin;
     const float mn = hn2[vmin];                                        // hr_norm.min(): the map x -> hn2 is monotone
     // np.var(hat2) in float32: mean (pairwise), deviations, squares, pairwise sum / n
-    const float m2 = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return hat2[hat[i]]; }, &bc), (float)n);
-    const float var_hat = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { const float d = __fsub_rn(hat2[hat[i]], m2); return __fmul_rn(d, d); }, &bc), (float)n);
-    // np.cov(hat2, hn2)[0, 1] in float64 (order-insensitive at this resolution)
-    double s_h = 0.0, s_n = 0.0;
-    for (int i = tid; i < n; i += NT) { s_h += (double)hat2[hat[i]]; s_n += (double)hn2[hr[i]]; }
-    const double avg_h = block_sum_f64(s_h, red) / n, avg_n = block_sum_f64(s_n, red) / n;
-    double s_c = 0.0;
-    for (int i = tid; i < n; i += NT) s_c += ((double)hat2[hat[i]] - avg_h) * ((double)hn2[hr[i]] - avg_n);
-    const double cov = block_sum_f64(s_c, red) / (double)(n - 1);
+    const float m2 = __fdiv_rn(pairwise_f32(n_hat, leaves_h, n_leaves_h, sums, [&](int i) { return hat2[hat[i]]; }, &bc), (float)n_hat);
+    const float var_hat = __fdiv_rn(pairwise_f32(n_hat, leaves_h, n_leaves_h, sums, [&](int i) { const float d = __fsub_rn(hat2[hat[i]], m2); return __fmul_rn(d, d); }, &bc), (float)n_hat);
+    double cov;
+    if (cov_part == nullptr) {
+        // np.cov(hat2, hn2)[0, 1] in float64 (order-insensitive at this resolution)
+        double s_h = 0.0, s_n = 0.0;
+        for (int i = tid; i < n; i += NT) { s_h += (double)hat2[hat[i]]; s_n += (double)hn2[hr[i]]; }
+        const double avg_h = block_sum_f64(s_h, red) / n, avg_n = block_sum_f64(s_n, red) / n;
+        double s_c = 0.0;
+        for (int i = tid; i < n; i += NT) s_c += ((double)hat2[hat[i]] - avg_h) * ((double)hn2[hr[i]] - avg_n);
+        cov = block_sum_f64(s_c, red) / (double)(n - 1);
+    } else {
+        // np.cov(resize(hat2), hn2)[0, 1]: the resize is linear with weights summing to one and hn2 is affine in the ground-truth byte
+        // (hn2 = (hr - x_min) / denom - mean), so cov = [sum r*hr - sum r * sum hr / n] / (n - 1) / denom with r = resize(hat)
+        const double* part = cov_part + (long)blockIdx.x * n_part * 2;
+        double s_r = 0.0, s_rh = 0.0;
+        for (int i = tid; i < n_part; i += NT) { s_r += part[2 * i]; s_rh += part[2 * i + 1]; }
+        s_r = block_sum_f64(s_r, red);
+        s_rh = block_sum_f64(s_rh, red);
+        double s_hr = 0.0;
+        s_hr = block_sum_f64((double)tid * (double)hist[tid], red);
+        cov = (s_rh - s_r * s_hr / (double)n) / (double)(n - 1) / (double)denom;
+    }
     const double amp = cov / (double)var_hat;
     // ---- rescale to the initial intensity (pssr/util.py:181-184)
     a_tab[tid] = __fmul_rn(__fsub_rn(hn2[tid], mn), base_max);
@@ -165,8 +190,8 @@ __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __re
     __syncthreads();
     const float a_mean = __fdiv_rn(pairwise_f32(n, leaves, n_leaves, sums, [&](int i) { return a_tab[hr[i]]; }, &bc), (float)n);
     double s_b = 0.0;
-    for (int i = tid; i < n; i += NT) s_b += b_tab[hat[i]];
-    const double b_mean = block_sum_f64(s_b, red) / n;
+    for (int i = tid; i < n_hat; i += NT) s_b += b_tab[hat[i]];
+    const double b_mean = block_sum_f64(s_b, red) / n_hat;
     const float a_div = __fdiv_rn(a_mean, base_mean);
     const double b_div = b_mean / (double)base_mean;
     {
@@ -179,8 +204,64 @@ __global__ __launch_bounds__(NT) void normalize_preds_kernel(const uint8_t* __re
     }
     __syncthreads();
     uint8_t* out_hr = out_hr_all + (long)blockIdx.x * n;
-    uint8_t* out_hat = out_hat_all + (long)blockIdx.x * n;
-    for (int i = tid; i < n; i += NT) { out_hr[i] = out_a[hr[i]]; out_hat[i] = out_b[hat[i]]; }
+    uint8_t* out_hat = out_hat_all + (long)blockIdx.x * n_hat;
+    for (int i = tid; i < n; i += NT) out_hr[i] = out_a[hr[i]];
+    for (int i = tid; i < n_hat; i += NT) out_hat[i] = out_b[hat[i]];
+}
+
+// ---- skimage.transform.resize(prediction, ground-truth shape) of pssr/util.py:179, restated in oracle/metrics_ref.py:resize_restated
+// (scikit-image >= 0.19 = scipy.ndimage: Gaussian pre-filter along shrinking axes, mirror boundary, then linear interpolation at
+// (i + 0.5) * in / out - 0.5 with mirrored indices; float64 arithmetic rounded to float32 per stage, as scipy does for float32 images)
+__device__ __forceinline__ int mirror_idx(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i = (i < 0 ? -i : i) % period;
+    return i >= n ? period - i : i;
+}
+template <typename S>
+__global__ void resize_gauss_axis_kernel(const S* __restrict__ in_all, float* __restrict__ out_all, int h, int w, double sigma, int axis) {
+    const S* in = in_all + (long)blockIdx.y * h * w;
+    float* out = out_all + (long)blockIdx.y * h * w;
+    const int r = (int)(4.0 * sigma + 0.5);
+    double wsum = 0.0;
+    for (int t = -r; t <= r; ++t) wsum += exp(-0.5 / (sigma * sigma) * (double)t * t);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)h * w; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        double acc = 0.0;
+        for (int t = -r; t <= r; ++t) {
+            const double wt = exp(-0.5 / (sigma * sigma) * (double)t * t) / wsum;
+            const long j = axis == 0 ? (long)mirror_idx(y + t, h) * w + x : (long)y * w + mirror_idx(x + t, w);
+            acc += wt * (double)in[j];
+        }
+        out[i] = (float)acc;
+    }
+}
+// per-workgroup partial sums [sum r, sum r * hr] over the ground-truth grid, r = float32(interpolated prediction)
+template <typename S>
+__global__ __launch_bounds__(NT) void resize_cov_sums_kernel(const S* __restrict__ src_all, int h, int w, const uint8_t* __restrict__ hr_all, int H,
+                                                             int W, double* __restrict__ part_all) {
+    __shared__ double red[NT];
+    const S* src = src_all + (long)blockIdx.y * h * w;
+    const uint8_t* hr = hr_all + (long)blockIdx.y * H * W;
+    const double fy = (double)h / (double)H, fx = (double)w / (double)W;
+    double s_r = 0.0, s_rh = 0.0;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < (long)H * W; i += (long)gridDim.x * NT) {
+        const int X = (int)(i % W), Y = (int)(i / W);
+        const double cy = ((double)Y + 0.5) * fy - 0.5, cx = ((double)X + 0.5) * fx - 0.5;
+        const double fly = floor(cy), flx = floor(cx);
+        const double ty = cy - fly, tx = cx - flx;
+        const int y0 = mirror_idx((int)fly, h), y1 = mirror_idx((int)fly + 1, h), x0 = mirror_idx((int)flx, w), x1 = mirror_idx((int)flx + 1, w);
+        const double v = (1.0 - ty) * (1.0 - tx) * (double)src[(long)y0 * w + x0] + (1.0 - ty) * tx * (double)src[(long)y0 * w + x1]
+                       + ty * (1.0 - tx) * (double)src[(long)y1 * w + x0] + ty * tx * (double)src[(long)y1 * w + x1];
+        const double r = (double)(float)v;
+        s_r += r;
+        s_rh += r * (double)hr[i];
+    }
+    const double a = block_sum_f64(s_r, red), b = block_sum_f64(s_rh, red);
+    if (threadIdx.x == 0) {
+        double* part = part_all + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        part[0] = a; part[1] = b;
+    }
 }
 
 
@@ -266,7 +347,7 @@ __global__ void __launch_bounds__(NT) image_metrics_finish_kernel(const uint8_t*
 }  // namespace
 
 extern "C" int64_t pssr_normalize_preds_workspace_bytes(int64_t pixels_per_image) {
-    return ((pixels_per_image / 32 + 16) * (int64_t)(sizeof(Leaf) + sizeof(float)) + 15) / 16 * 16;
+    return ((pixels_per_image / 32 + 16) * (int64_t)(2 * sizeof(Leaf) + sizeof(float)) + 15) / 16 * 16;
 }
 
 extern "C" int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat, uint8_t* hr_norm, uint8_t* hr_hat_norm, int n_images,
@@ -275,7 +356,53 @@ extern "C" int pssr_normalize_preds_u8(const uint8_t* hr, const uint8_t* hr_hat,
     PSSR_CHECK(pixels_per_image >= 2 && pixels_per_image < (1L << 24), PSSR_ERR_ARG, "normalize_preds: %ld pixels per image (2 .. 2^24 - 1)", (long)pixels_per_image);
     PSSR_CHECK(pmin >= 0.f && pmax <= 100.f && pmin <= pmax, PSSR_ERR_ARG, "normalize_preds: percentiles");
     hipLaunchKernelGGL(normalize_preds_kernel, dim3(n_images), dim3(NT), 0, (hipStream_t)s, hr, hr_hat, hr_norm, hr_hat_norm, (int)pixels_per_image,
-                       pmin, pmax, (char*)workspace, (long)pssr_normalize_preds_workspace_bytes(pixels_per_image));
+                       (int)pixels_per_image, pmin, pmax, (char*)workspace, (long)pssr_normalize_preds_workspace_bytes(pixels_per_image), nullptr, 0);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+// ---- prediction and ground truth of different sizes (pssr/util.py:176-179)
+constexpr int COV_PARTS = 256;
+static inline int64_t nr_ws_norm(int64_t px_big) { return ((px_big / 32 + 16) * (int64_t)(2 * sizeof(Leaf) + sizeof(float)) + 15) / 16 * 16; }
+
+extern "C" int64_t pssr_normalize_preds_resized_workspace_bytes(int n_images, int H, int W, int h, int w) {
+    if (n_images <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return 0;
+    const int64_t big = (int64_t)H * W > (int64_t)h * w ? (int64_t)H * W : (int64_t)h * w;
+    return n_images * (nr_ws_norm(big) + (int64_t)COV_PARTS * 2 * sizeof(double) + 2 * (int64_t)h * w * sizeof(float));
+}
+
+extern "C" int pssr_normalize_preds_resized_u8(const uint8_t* hr, int H, int W, const uint8_t* hr_hat, int h, int w, uint8_t* hr_norm,
+                                               uint8_t* hr_hat_norm, int n_images, float pmin, float pmax, void* workspace, pssr_stream_t s) {
+    PSSR_CHECK(hr && hr_hat && hr_norm && hr_hat_norm && workspace && n_images > 0, PSSR_ERR_ARG, "normalize_preds_resized: null pointer / no images");
+    PSSR_CHECK(H > 0 && W > 0 && h > 0 && w > 0 && (long)H * W >= 2 && (long)H * W < (1L << 24) && (long)h * w >= 2 && (long)h * w < (1L << 24), PSSR_ERR_ARG,
+               "normalize_preds_resized: image sizes %dx%d / %dx%d (2 .. 2^24 - 1 pixels)", H, W, h, w);
+    PSSR_CHECK(pmin >= 0.f && pmax <= 100.f && pmin <= pmax, PSSR_ERR_ARG, "normalize_preds_resized: percentiles");
+    const int64_t big = (int64_t)H * W > (int64_t)h * w ? (int64_t)H * W : (int64_t)h * w;
+    char* ws = (char*)workspace;
+    char* ws_norm = ws;
+    double* parts = (double*)(ws + n_images * nr_ws_norm(big));
+    float* fa = (float*)(parts + (int64_t)n_images * COV_PARTS * 2);
+    float* fb = fa + (int64_t)n_images * h * w;
+    hipStream_t st = (hipStream_t)s;
+    const double sy = ((double)h / H - 1.0) / 2.0, sx = ((double)w / W - 1.0) / 2.0;
+    const bool shrink = H < h || W < w;
+    const float* filtered = nullptr;
+    const dim3 fgrid((unsigned)(((long)h * w + 255) / 256 < 1024 ? ((long)h * w + 255) / 256 : 1024), n_images);
+    if (shrink) {
+        // axis 0 first, then axis 1 (scipy.ndimage.gaussian_filter); an axis that does not shrink has sigma 0 and is skipped
+        if (sy > 0.0) {
+            hipLaunchKernelGGL(resize_gauss_axis_kernel<uint8_t>, fgrid, dim3(256), 0, st, hr_hat, fa, h, w, sy, 0);
+            filtered = fa;
+            if (sx > 0.0) { hipLaunchKernelGGL(resize_gauss_axis_kernel<float>, fgrid, dim3(256), 0, st, (const float*)fa, fb, h, w, sx, 1); filtered = fb; }
+        } else {
+            hipLaunchKernelGGL(resize_gauss_axis_kernel<uint8_t>, fgrid, dim3(256), 0, st, hr_hat, fa, h, w, sx, 1);
+            filtered = fa;
+        }
+    }
+    if (filtered) hipLaunchKernelGGL(resize_cov_sums_kernel<float>, dim3(COV_PARTS, n_images), dim3(NT), 0, st, filtered, h, w, hr, H, W, parts);
+    else hipLaunchKernelGGL(resize_cov_sums_kernel<uint8_t>, dim3(COV_PARTS, n_images), dim3(NT), 0, st, hr_hat, h, w, hr, H, W, parts);
+    hipLaunchKernelGGL(normalize_preds_kernel, dim3(n_images), dim3(NT), 0, st, hr, hr_hat, hr_norm, hr_hat_norm, H * W, h * w, pmin, pmax, ws_norm,
+                       (long)nr_ws_norm(big), (const double*)parts, COV_PARTS);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

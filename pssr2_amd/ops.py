@@ -323,6 +323,16 @@ def crappify_poisson(x, intensity, gain, spread, seed, tile_offset, flags, out=N
     return out
 
 
+def crappify_poisson_samples(x, samples, intensity, gain, flags, out=None):
+    """Poisson mix with injected samples (f64, same shape as x): pssr_crappify_poisson_samples."""
+    out = torch.empty_like(x) if out is None else out
+    if samples.dtype != torch.float64 or samples.numel() != x.numel():
+        raise ValueError("samples: float64, one per element of x")
+    L.check(L.lib().pssr_crappify_poisson_samples(L.ptr(x), L.ptr(samples.contiguous()), L.ptr(out), C.c_int64(x.numel()), C.c_double(intensity),
+                                                  C.c_double(gain), flags, L.stream_ptr()), "pssr_crappify_poisson_samples")
+    return out
+
+
 def gaussian_blur(x, sigma, gain, flags):
     h, w = x.shape[-2:]
     planes = x.numel() // (h * w)
@@ -538,6 +548,21 @@ def normalize_preds_u8(hr, hr_hat, pmin=0.1, pmax=99.9):
     a, b = torch.empty_like(hr), torch.empty_like(hr_hat)
     L.check(lib.pssr_normalize_preds_u8(L.ptr(hr), L.ptr(hr_hat), L.ptr(a), L.ptr(b), n, C.c_int64(px), C.c_float(pmin), C.c_float(pmax), L.ptr(ws),
                                         L.stream_ptr()), "pssr_normalize_preds_u8")
+    return a, b
+
+
+def normalize_preds_resized_u8(hr, hr_hat, pmin=0.1, pmax=99.9):
+    """uint8 device tensors [n, H, W] / [n, h, w] of different sizes (pssr/util.py:176-179): pssr_normalize_preds_resized_u8."""
+    if hr.dtype != torch.uint8 or hr_hat.dtype != torch.uint8 or hr.dim() != 3 or hr_hat.dim() != 3 or hr.shape[0] != hr_hat.shape[0] or not hr.is_cuda:
+        raise ValueError("normalize_preds_resized_u8 needs two uint8 device tensors [n, H, W] and [n, h, w]")
+    hr, hr_hat = hr.contiguous(), hr_hat.contiguous()
+    n, (H, W), (h, w) = hr.shape[0], hr.shape[1:], hr_hat.shape[1:]
+    lib = L.lib()
+    lib.pssr_normalize_preds_resized_workspace_bytes.restype = C.c_int64
+    ws = torch.empty(lib.pssr_normalize_preds_resized_workspace_bytes(n, H, W, h, w), dtype=torch.uint8, device=hr.device)
+    a, b = torch.empty_like(hr), torch.empty_like(hr_hat)
+    L.check(lib.pssr_normalize_preds_resized_u8(L.ptr(hr), H, W, L.ptr(hr_hat), h, w, L.ptr(a), L.ptr(b), n, C.c_float(pmin), C.c_float(pmax), L.ptr(ws),
+                                                L.stream_ptr()), "pssr_normalize_preds_resized_u8")
     return a, b
 
 

@@ -210,21 +210,27 @@ def _patch_images(batched, n_cols, n_rows, overlap, margin):
 def normalize_preds(hr, hr_hat, pmin: float = 0.1, pmax: float = 99.9):
     r"""Normalizes prediction image intensities to ground truth for fair benchmarking (pssr/util.py:139-191), on the MI355X
     (csrc/metrics.hip, bit-exact with the reference's numpy arithmetic).  ``hr`` / ``hr_hat``: uint8 arrays or tensors of the
-    same shape ``[..., H, W]`` -- what ``test_metrics`` and ``predict_images(norm=True)`` pass (the reference's resize of
-    mismatched sizes goes through scikit-image and is not provided).  Returns uint8 numpy arrays like the reference."""
+    same shape ``[..., H, W]`` -- what ``test_metrics`` and ``predict_images(norm=True)`` pass -- or with image sizes that differ
+    (pssr/util.py:176-179: the covariance is then taken against ``skimage.transform.resize(prediction, ground-truth shape)``, here
+    its scikit-image >= 0.19 / scipy.ndimage definition evaluated on the device; each output keeps its own size).  Returns uint8
+    numpy arrays like the reference."""
     import numpy as np
     from . import ops
     dev = hr_hat.device if isinstance(hr_hat, torch.Tensor) and hr_hat.is_cuda else (hr.device if isinstance(hr, torch.Tensor) and hr.is_cuda else "cuda")
     a, b = (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(t)) for t in (hr, hr_hat))
     if a.dim() != b.dim():
         raise ValueError(f"hr and hr_hat must have the same number of dimensions. Dimension lengths are {tuple(a.shape)} and {tuple(b.shape)} respectively.")
-    if a.shape != b.shape:
-        raise NotImplementedError("normalize_preds on the MI355X needs images of equal size (the reference resizes through scikit-image)")
     if a.dtype != torch.uint8 or b.dtype != torch.uint8:
         raise TypeError("normalize_preds on the MI355X takes uint8 images (the output of _pred_array), as test_metrics passes them")
-    shape = a.shape
     if a.dim() < 2:
         raise ValueError("images need at least 2 dimensions")
+    if a.shape != b.shape:
+        n_a, n_b = a.numel() // (a.shape[-1] * a.shape[-2]), b.numel() // (b.shape[-1] * b.shape[-2])
+        if n_a != n_b:
+            raise ValueError(f"hr and hr_hat must have the same number of images. Received {n_a} and {n_b} images respectively.")
+        a2, b2 = ops.normalize_preds_resized_u8(a.to(dev).reshape(-1, *a.shape[-2:]), b.to(dev).reshape(-1, *b.shape[-2:]), pmin, pmax)
+        return a2.reshape(a.shape).cpu().numpy(), b2.reshape(b.shape).cpu().numpy()
+    shape = a.shape
     a2, b2 = ops.normalize_preds_u8(a.to(dev).reshape(-1, *shape[-2:]), b.to(dev).reshape(-1, *shape[-2:]), pmin, pmax)
     return a2.reshape(shape).cpu().numpy(), b2.reshape(shape).cpu().numpy()
 

@@ -133,3 +133,31 @@ def test_test_metrics_values_match_oracle_on_the_arrays_it_evaluated():
         assert abs(per["pixel"][k] - pixel_metric(mse, 255)) <= 1e-9
         assert abs(per["psnr"][k] - M.psnr(hr[0], hat[0])) < 1e-9
         assert abs(per["ssim"][k] - M.ssim(hr[0].squeeze(), hat[0].squeeze())) < 1e-10
+
+
+@pytest.mark.parametrize("hr_shape,hat_shape", [((2, 128, 128), (2, 32, 32)), ((1, 64, 96), (1, 256, 384)), ((3, 100, 37), (3, 41, 90)),
+                                                  ((1, 512, 512), (1, 128, 128)), ((2, 40, 40), (2, 40, 56))])
+def test_normalize_preds_with_a_prediction_of_another_size_vs_oracle(hr_shape, hat_shape):
+    """pssr/util.py:176-179 on the device (pssr_normalize_preds_resized_u8) against the numpy / scipy restatement: the ground-truth
+    side is bit-exact (it does not depend on the resize); the prediction side is a 256-entry table scaled by the covariance amplitude,
+    whose resize the device evaluates from the raw bytes in float64 instead of from mean-removed float32 values -- equal up to the last
+    bits of `amp`, so a byte may land on the other side of a truncation: <= 1 grey level on <= 0.5 % of the pixels."""
+    from oracle import metrics_ref as M
+    from pssr2_amd import ops
+    from pssr2_amd.util import normalize_preds
+    rng = np.random.default_rng(sum(hr_shape) + sum(hat_shape))
+    base = rng.normal(120, 40, size=hr_shape)
+    from scipy import ndimage as ndi
+    base = ndi.gaussian_filter(base, (0, 2, 2)) * 2.5 - 180            # spatial structure, so that the covariance is not noise
+    hr = np.clip(base + rng.normal(0, 5, size=hr_shape), 0, 255).astype(np.uint8)
+    zoom = (1, hat_shape[1] / hr_shape[1], hat_shape[2] / hr_shape[2])
+    hat = np.clip(0.7 * ndi.zoom(base, zoom, order=1, grid_mode=True, mode="mirror") + 30 + rng.normal(0, 6, size=hat_shape), 0, 255).astype(np.uint8)
+    want_a, want_b = M.normalize_preds(hr, hat)
+    a, b = ops.normalize_preds_resized_u8(torch.tensor(hr).cuda(), torch.tensor(hat).cuda())
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    np.testing.assert_array_equal(a, want_a)
+    d = np.abs(b.astype(int) - want_b.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 5e-3, (d.max(), (d > 0).mean())
+    assert want_b.std() > 10                                           # a real image came out, not a constant
+    a3, b3 = normalize_preds(hr, hat)                                  # the reference-shaped entry point routes here
+    assert np.array_equal(a3, a) and np.array_equal(b3, b) and b3.shape == hat_shape

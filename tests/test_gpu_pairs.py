@@ -147,3 +147,84 @@ def test_device_saltpepper_and_blur_spread():
     _, lr = DevicePairGenerator(4, MultiCrappifier(Blur(1.0, spread=0.3), SaltPepper(2.0)), seed=1)(hr)
     lr = lr.cpu().numpy()
     assert lr.min() >= 0 and lr.max() <= 255 and np.array_equal(lr, np.round(lr)) and 0.005 < ((lr == 0) | (lr == 255)).mean() < 0.05
+
+
+def _device_lr(g, name):
+    """The fixture's HR stack through the device geometry-free path: host crop / pad / rot (oracle restatement, pinned by the same
+    fixtures) + the Pillow-exact device reduction.  Returns float32 LR [1, C, h, w] on the device, before any crappifier."""
+    from oracle import pairs_ref as P
+    from pssr2_amd import ops
+    hr_res, scale, seed, has_rot, rot90, flip = (int(v) for v in g[f"{name}_meta"])
+    rot = [bool(rot90), (1, 2) if flip == 3 else flip] if has_rot else False
+    hr = P.augment(P.pad_image(P.square_crop(g[f"{name}_hr_in"], hr_res), hr_res), rot)
+    hr_d = torch.tensor(np.ascontiguousarray(hr)).cuda()[None]
+    return ops.u8_to_f32(ops.bilinear_down_u8(hr_d, hr_res // scale, hr_res // scale)), seed
+
+
+@pytest.mark.parametrize("name,intensity,gain", [("poisson", 1, 0), ("poisson_mix", 0.5, 4)])
+def test_poisson_with_injected_reference_samples_is_bit_exact(golden, name, intensity, gain):
+    """c3's crappifier: x*(1-i) + Poisson(clip(x, 0, inf))*i + gain -> np.round -> clip (pssr/crappifiers.py:81-86, pssr/data.py:487)
+    on the device with the reference's own draws (numpy's frozen legacy stream, re-drawn with the fixture's seed) == the reference's
+    LR tile, bit for bit -- the integer part of the Poisson path, which the Philox tests cannot pin."""
+    from pssr2_amd import ops
+    g = golden("pairs.npz")
+    lr, seed = _device_lr(g, name)
+    np.random.seed(seed)
+    samples = np.random.poisson(np.clip(lr.cpu().numpy(), 0, np.inf))            # the reference's first and only draw (rot was given)
+    out = ops.crappify_poisson_samples(lr, torch.tensor(samples.astype(np.float64)).cuda(), intensity, gain, ops.ROUND_CLIP)
+    assert np.array_equal(out.cpu().numpy()[0], g[f"{name}_lr"])
+
+
+def test_multicrappifier_chain_with_injected_draws_is_bit_exact(golden):
+    """MultiCrappifier(AdditiveGaussian(13), Poisson()) with clip (pssr/crappifiers.py:26-43) as two device stages fed the reference's
+    draws in the reference's order: N(0, 13) field, clip, then Poisson of the clipped float64 image."""
+    from pssr2_amd import ops
+    g = golden("pairs.npz")
+    lr, seed = _device_lr(g, "multi")
+    np.random.seed(seed)
+    noise = np.random.normal(0, 13, lr.shape[1:])
+    x1 = ops.crappify_gaussian(lr, 0.0, 0.0, 0.0, 0, 0, ops.CLIP, noise=torch.tensor(noise).cuda()[None].contiguous())
+    x1_64 = np.clip(lr.cpu().numpy()[0].astype(np.float32) + noise, 0, 255)      # float32 + float64 -> float64, as numpy does upstream
+    assert np.array_equal(x1.cpu().numpy()[0], x1_64.astype(np.float32))
+    samples = np.random.poisson(np.clip(x1_64, 0, np.inf))
+    out = ops.crappify_poisson_samples(x1, torch.tensor(samples.astype(np.float64)).cuda()[None].contiguous(), 1, 0, ops.ROUND_CLIP)
+    assert np.array_equal(out.cpu().numpy()[0], g["multi_lr"])
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "poisson"])
+def test_spread_draw_order_with_injected_draws(kind):
+    """spread > 0: AdditiveGaussian draws its scalar sigma BEFORE the field (pssr/crappifiers.py:62-64), Poisson draws the field first and
+    the scalar mix afterwards (:81-86).  The host classes (reference order) against the device kernels fed draws made in that order."""
+    from pssr2_amd import ops
+    from pssr2_amd.crappifiers import AdditiveGaussian, Poisson
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(1, 48, 48)).astype(np.uint8)
+    x = torch.tensor(img.astype(np.float32)).cuda()[None]
+    np.random.seed(77)
+    if kind == "gaussian":
+        ref = AdditiveGaussian(10, 2, 3).crappify(img)
+        np.random.seed(77)
+        sigma = max(np.random.normal(10, 3), 0)
+        noise = np.random.normal(2, sigma, img.shape)
+        out = ops.crappify_gaussian(x, 0.0, 0.0, 0.0, 0, 0, ops.ROUND_CLIP, noise=torch.tensor(noise).cuda()[None].contiguous())
+    else:
+        ref = Poisson(0.7, 1.5, 0.2).crappify(img)
+        np.random.seed(77)
+        samples = np.random.poisson(np.clip(img, 0, np.inf))
+        mix = max(np.random.normal(0.7, 0.2), 0)
+        out = ops.crappify_poisson_samples(x, torch.tensor(samples.astype(np.float64)).cuda()[None].contiguous(), mix, 1.5, ops.ROUND_CLIP)
+    assert np.array_equal(out.cpu().numpy()[0], np.clip(np.round(ref), 0, 255).astype(np.float32))
+
+
+def test_device_spread_statistics():
+    """Device RNG with spread > 0: one sigma (Gaussian) / one mix (Poisson) per tile, max(N(intensity, spread), 0)."""
+    from pssr2_amd import ops
+    x = torch.full((512, 1, 32, 32), 100.0, device="cuda")
+    a = ops.crappify_gaussian(x, 10.0, 0.0, 2.0, seed=9, tile_offset=0, flags=0)
+    per_tile = (a - 100.0).double().flatten(1).std(dim=1).cpu().numpy()
+    # per-tile std estimates scatter by sigma / sqrt(2 * 1024) ~ 0.22 around each tile's own sigma
+    assert abs(per_tile.mean() - 10.0) < 0.3 and abs(per_tile.std() - 2.0) < 0.3
+    p = ops.crappify_poisson(x, 0.5, 0.0, 0.2, seed=9, tile_offset=0, flags=0)
+    # x*(1-m) + y*m: per-tile std = m * sqrt(100)
+    mix = (p - 100.0).double().flatten(1).std(dim=1).cpu().numpy() / 10.0
+    assert abs(mix.mean() - 0.5) < 0.03 and abs(mix.std() - 0.2) < 0.03
