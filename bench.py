@@ -113,6 +113,62 @@ class ConvTimer:
                     bytes_per_launch=tot_b / n)
 
 
+class HbmTimer:
+    """HIP-event timing of the HBM-bound kernels north_star asks a GB/s figure for: the reconstruction head (``Reconstruction.conv`` on the
+    pixel-shuffled 64-channel HR tensor: forward, and its one-pass backward) and the fused AdamW update.  Algorithmic bytes: the head's
+    activation read once (+ its gradient written once in the backward) plus the f32 HR images; AdamW 28 B per parameter (p, g, m, v
+    read; p, m, v written)."""
+
+    def __init__(self):
+        self.rec = {}
+        self.orig = {}
+
+    def _wrap(self, name, fn, nbytes):
+        timer = self
+
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            timer.rec.setdefault(name, []).append((e0, e1, float(nbytes(*a, **kw))))
+            return r
+        return timed
+
+    def install(self):
+        from pssr2_amd import ops
+        esz = lambda code: 4 if code == 0 else 2
+        # head_conv_fwd(act, blk, weight, bias, out, n, h, w, cin, cout, out_scale, out_shift, dtype, ...): h, w are HR sizes
+        fwd_b = lambda act, blk, wt, b, out, n, h, w, cin, cout, osc, osh, dt, **kw: n * h * w * (cin * esz(dt) + 4 * cout)
+        # head_conv_bwd_rows(g, g_scale, weight, act, dact, blk, dw_rows, bias_rows, n, h, w, cin, cout, dtype)
+        bwd_b = lambda g, gs, wt, act, dact, blk, dwr, br, n, h, w, cin, cout, dt: n * h * w * (2 * cin * esz(dt) + 4 * cout)
+        adam_b = lambda p, *a, **kw: 28 * p.numel()
+        for name, nb in (("head_conv_fwd", fwd_b), ("head_conv_bwd_rows", bwd_b), ("adamw_step_dev", adam_b), ("adamw_step", adam_b)):
+            self.orig[name] = getattr(ops, name)
+            setattr(ops, name, self._wrap(name, self.orig[name], nb))
+
+    def remove(self):
+        from pssr2_amd import ops
+        for name, fn in self.orig.items():
+            setattr(ops, name, fn)
+
+    def objects(self):
+        out = []
+        label = {"head_conv_fwd": "head_fwd_kernel (Reconstruction.conv forward on the pixel-shuffled HR tensor)",
+                 "head_conv_bwd_rows": "head_bwd_kernel (its data + weight gradient + bias sums in one pass)",
+                 "adamw_step_dev": "adamw_kernel (fused AdamW over the flat parameter buffer)", "adamw_step": "adamw_kernel (fused AdamW over the flat parameter buffer)"}
+        for name, ev in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            nb = sum(e[2] for e in ev)
+            if ms <= 0:
+                continue
+            gbs = nb / (ms * 1e-3) / 1e9
+            out.append({"kernel": label[name], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 1),
+                        "algorithmic_bytes_per_launch": round(nb / len(ev)), "traffic": None})
+        return out
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -266,6 +322,9 @@ def main():
     n_tiles = args.tiles if args.mode != "sheet" else 0
     need = (args.warmup + args.steps) * args.batch
     tiles_np = make_tiles(n_tiles, hr_res, args.channels, rank_env, args.tile_workers) if n_tiles else None      # before CUDA: the pool forks
+    extras = (rank_env == 0 and world_env == 1 and args.mode == "train" and not args.no_extras and args.model == "resunet" and args.channels == 1
+              and args.lr_res == 128)
+    tiles_c4 = make_tiles(72, 1024, 3, 77, args.tile_workers) if extras else None      # BASELINE config 4: 3-frame 1024^2 HR tiles
 
     from pssr2_amd import distributed as D
     force_dev = os.environ.get("PSSR_BENCH_FORCE_DEVICE")       # rehearsal knob: several gloo ranks on ONE card
@@ -305,8 +364,9 @@ def main():
     loss_fn = SSIMLoss(channels=args.channels, mix=0.8)
     quiet = open(os.devnull, "w")
 
-    def run_train(model, dataset, batch, warmup, steps):
+    def run_train(model, dataset, batch, warmup, steps, dataloader_kwargs=None, loss=None):
         """train_paired until the clock has seen warmup + steps steps; returns seconds for the timed steps (max over ranks)."""
+        loss = loss_fn if loss is None else loss
         opt = FusedAdamW(model.parameters(), lr=1e-3)
         clock = StepClock(warmup, steps, barrier)
         per_epoch = (len(dataset) - len(dataset.val_idx)) // world // batch
@@ -314,7 +374,7 @@ def main():
         old = sys.stdout
         sys.stdout = quiet                               # the driver prints per-epoch lines (as upstream); the bench prints ONE line
         try:
-            train_paired(model, dataset, batch, loss_fn, opt, epochs, device=dev, callbacks=[clock])
+            train_paired(model, dataset, batch, loss, opt, epochs, device=dev, callbacks=[clock], dataloader_kwargs=dataloader_kwargs)
         except _Done:
             pass
         finally:
@@ -374,26 +434,30 @@ def main():
         per_step, steps_done = sheet_tiles, args.steps
 
     # ---- roofline of the dominant kernel set: the same kernels once more, one at a time on the launch stream, HIP events
-    conv = None
+    conv, hbm_objects = None, []
     if rank == 0 and args.dtype in ("bf16", "fp16") and args.mode != "sheet":
         eng = model._engine
         side, eng.side_wgrad = eng.side_wgrad, False
         eng.mark_weights_changed()
         timer.install()
+        hbm = HbmTimer()
+        hbm.install()
         x = torch.rand(args.batch, args.channels, args.lr_res, args.lr_res, device=dev) * 255
         tgt = torch.rand(args.batch, args.channels, hr_res, hr_res, device=dev)
         for _ in range(2):
             if args.mode == "train":
                 model.train()
                 loss_fn(model(x) / 255, tgt).backward()
-                for p in model.parameters():
-                    p.grad = None
+                opt.step()
+                opt.zero_grad()
             else:
                 model.eval()
                 with torch.no_grad():
                     model(x)
         torch.cuda.synchronize()
         timer.remove()
+        hbm.remove()
+        hbm_objects = hbm.objects()
         eng.side_wgrad = side
         eng.mark_weights_changed()
         conv = timer.summary()
@@ -431,10 +495,12 @@ def main():
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv["bytes_per_launch"]),
-                               "launches": conv["launches"], "avg_launch_us": round(conv["avg_us"], 1),
+                               "launches": conv["launches"] // 2, "instrumented_passes": 2, "avg_launch_us": round(conv["avg_us"], 1),
                                "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2),
                                "measured_in": "instrumented eager passes after the timed region: the same kernels one at a time on the launch stream, HIP events "
                                               "(the timed region replays them from a hipGraph with the weight-gradient kernels overlapping on a second stream)"}
+        if hbm_objects:
+            res["roofline_hbm"] = hbm_objects
 
     # ---- N > 1: what the gradient exchange costs and how much of it the backward pass hides
     if world > 1 and args.mode == "train":
@@ -461,7 +527,7 @@ def main():
                            "split_graph": bool(stp is not None and stp.graph2 is not None), "ranks_seen": sorted(ranks),
                            "bus_GBps": round(2 * (world - 1) / world * flat.numel() * 4 / (comm_ms * 1e-3) / 1e9, 1)}
     # ---- extra legs (rank 0 of a 1-GPU run): inference, sheet, exact-f32 training, CPU oracle
-    if rank == 0 and world == 1 and args.mode == "train" and not args.no_extras and args.model == "resunet" and args.channels == 1:
+    if extras:
         try:
             infer_dt = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "f32"}[model._engine.storage_dtype(False)]
             ids = DeviceTileDataset(tiles_dev, hr_res=hr_res, lr_scale=4, crappifier=crap, val_split=1.0, rotation=False, device=dev, seed=99)
@@ -502,6 +568,50 @@ def main():
                                 "algorithmic_tflops": round(v32 * TRAIN_GFLOP_PER_TILE / 1e3, 2),
                                 "frac_of_f32_mfma_peak": round(v32 * TRAIN_GFLOP_PER_TILE / 1e3 / PEAK_F32_TFLOPS, 4)}
             del model32, ds32
+            # ---- c3: RDResUNet, Poisson crappifier, bf16, batch 32 per GPU (321.45 GFLOP per tile)
+            torch.manual_seed(0)
+            model_rd = RDResUNet().to(dev)
+            model_rd.compute_dtype = torch.bfloat16
+            ds_rd = DeviceTileDataset(tiles_dev[:1024], hr_res=hr_res, lr_scale=4, crappifier=Poisson(), val_split=0.1, rotation=True, device=dev, seed=8)
+            t_rd, _ = run_train(model_rd, ds_rd, 32, 3, 8)
+            v_rd = 32 * 8 / t_rd
+            res["rd_train"] = {"metric": f"HR tiles/sec ({hr_res}^2 4xSR) train", "value": round(v_rd, 2), "unit": "HR tiles/s", "dtype": "bf16",
+                               "ms_per_step": round(1e3 * t_rd / 8, 3),
+                               "config": "BASELINE config 3 on one GPU: RDResUNet 1-ch 128^2->512^2, Poisson() device crappifier, MS-SSIM+L1, FusedAdamW, "
+                                         "batch 32, train_paired (hipGraph replay), 8 timed steps",
+                               "roofline": whole_pass_roofline(round(v_rd * 321.45 / 1e3, 2), "whole training step (pair generation, forward, loss, backward, "
+                                                               "optimizer); algorithmic FLOPs of the convolutions (SURVEY.md 8d: 321.45 GFLOP per tile)")}
+            del model_rd, ds_rd
+            # ---- c4: ResUNet 3-ch multiframe, 256^2 -> 1024^2, MS-SSIM+L1, fp16 storage + dynamic loss scaling, batch 8 per GPU
+            torch.manual_seed(0)
+            model_c4 = ResUNet(channels=3).to(dev)
+            model_c4.compute_dtype = torch.float16
+            ds_c4 = DeviceTileDataset(torch.from_numpy(tiles_c4).to(dev), hr_res=1024, lr_scale=4, crappifier=crap, val_split=0.1, rotation=True, device=dev,
+                                      seed=9)
+            t_c4, _ = run_train(model_c4, ds_c4, 8, 3, 5, loss=SSIMLoss(channels=3, mix=0.8))
+            v_c4 = 8 * 5 / t_c4
+            res["c4_train"] = {"metric": "HR tiles/sec (1024^2 4xSR) train", "value": round(v_c4, 2), "unit": "HR tiles/s", "dtype": "fp16",
+                               "ms_per_step": round(1e3 * t_c4 / 5, 3),
+                               "config": "BASELINE config 4 on one GPU: ResUNet 3-ch (3 frames) 256^2->1024^2, AdditiveGaussian(13), MS-SSIM+L1 over 3 channels, "
+                                         "fp16 storage + dynamic loss scaling, FusedAdamW, batch 8, train_paired (hipGraph replay), 5 timed steps",
+                               "roofline": whole_pass_roofline(round(v_c4 * 774.65 / 1e3, 2), "whole training step; algorithmic FLOPs of the convolutions "
+                                                               "(SURVEY.md 8d: 774.65 GFLOP per 1024^2 tile)")}
+            del model_c4, ds_c4
+            # ---- the drop-in API fed by a HOST dataset (what a user of the reference passes: Pillow reduction + numpy crappifier on the CPU,
+            # DataLoader workers): PCIe-inclusive, never the headline value
+            from pssr2_amd.data import ArrayDataset
+            workers = max(2, min(12, (os.cpu_count() or 8) - 4))
+            hds = ArrayDataset(tiles_np[:448], hr_res=hr_res, lr_scale=4, crappifier=crap, val_split=0.05, rotation=True)
+            model_h = make_model(args.dtype)
+            t_h, _ = run_train(model_h, hds, args.batch, 4, 8, dataloader_kwargs=dict(num_workers=workers, pin_memory=True, persistent_workers=True,
+                                                                                   prefetch_factor=4, multiprocessing_context="spawn"))
+            v_h = args.batch * 8 / t_h
+            res["api_host"] = {"metric": f"HR tiles/sec ({hr_res}^2 4xSR) train", "value": round(v_h, 2), "unit": "HR tiles/s", "dtype": args.dtype,
+                               "ms_per_step": round(1e3 * t_h / 8, 3), "frac_of_headline": round(v_h / tiles_per_s, 3),
+                               "config": f"train_paired(model, ArrayDataset, ...) with dataloader_kwargs num_workers={workers}, pin_memory: pairs made on the "
+                                         f"host CPU (Pillow reduction + numpy AdditiveGaussian, as the reference's ImageDataset), one pinned host-to-device "
+                                         f"copy + one hipGraph replay per batch; PCIe-inclusive; {os.cpu_count()} hardware threads present, 8 timed steps"}
+            del model_h, hds
         except Exception as e:                                     # an extra leg must not take the headline line with it
             res["extras_error"] = f"{type(e).__name__}: {e}"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "resunet":

@@ -24,6 +24,7 @@ from . import distributed as D
 from .util import SSIMLoss as _SSIMLoss
 
 
+_GRAPH_PRIO = os.environ.get("PSSR_GRAPH_PRIO", "0") != "0"
 LAST_TRAIN_STEPPER = None      # the stepper of the most recent train_paired call (bench.py reads its communication statistics)
 
 
@@ -40,6 +41,55 @@ def supports(model, dataset, device):
         return False
     return (enabled() and getattr(model, "_engine", None) is not None and hasattr(dataset, "device_batch") and hasattr(dataset, "draw_items")
             and torch.device(device).type == "cuda" and getattr(dataset, "extra_hr_files", None) is None)
+
+
+def supports_host(model, dataset, device):
+    """Replay for HOST-fed batches: any dataset that goes through a DataLoader (the reference's ImageDataset / SlidingDataset, their
+    crappifiers running on the CPU, optionally in worker processes) with an engine-backed model on the GPU.  The step is captured once
+    over static input buffers; a batch then costs one asynchronous host-to-device copy and one graph replay instead of ~400 ctypes
+    launches (pssr/train.py:75-103, pssr/predict.py:49-61).  PSSR_HOST_GRAPH=0 keeps the launch-by-launch loop."""
+    if getattr(model, "sync_bn", False) and D.rank_world()[1] > 1:
+        return False
+    return (enabled() and os.environ.get("PSSR_HOST_GRAPH", "1") != "0" and getattr(model, "_engine", None) is not None
+            and torch.device(device).type == "cuda" and getattr(dataset, "extra_hr_files", None) is None)
+
+
+class _HostFeed:
+    """Static device inputs of a captured graph, refilled from host batches: the host-to-device copy of batch i + 1 runs on its own
+    stream into one of two staging buffers while the graph of batch i is still running; a device-to-device copy (~15 us for a c2
+    batch) moves it into the graph's buffers in stream order.  Pinned host tensors (DataLoader(pin_memory=True)) copy without a
+    host-side staging pass."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.static, self.stage, self.free_ev, self.keep, self.k = None, [None, None], [None, None], [None, None], 0
+
+    def matches(self, tensors):
+        return self.static is not None and all(t.shape == s.shape for t, s in zip(tensors, self.static)) and len(tensors) == len(self.static)
+
+    def allocate(self, tensors):
+        mk = lambda: [torch.empty(t.shape, dtype=torch.float32, device=self.device) for t in tensors]
+        self.static, self.stage = mk(), [mk(), mk()]
+
+    def push(self, tensors):
+        k = self.k
+        self.k ^= 1
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.copy_stream):
+            if self.free_ev[k] is not None:
+                self.copy_stream.wait_event(self.free_ev[k])           # the previous content of this staging buffer has been consumed
+            for dst, src in zip(self.stage[k], tensors):
+                dst.copy_(src, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        main.wait_event(ready)
+        for dst, src in zip(self.static, self.stage[k]):
+            dst.copy_(src)
+        done = torch.cuda.Event()
+        done.record(main)
+        self.free_ev[k], self.keep[k] = done, tensors                  # (the host tensors stay alive until their copy has run)
+        return self.static
 
 
 class _Cursor:
@@ -73,7 +123,7 @@ class TrainStepper:
 
     WARM = 2
 
-    def __init__(self, model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, capacity, device):
+    def __init__(self, model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, capacity, device, host=False):
         from .optim import FusedAdamW
         self.model, self.dataset, self.batch, self.loss_fn, self.optim = model, dataset, batch_size, loss_fn, optim
         self.clamp, self.image_range, self.scaler = clamp, image_range, scaler
@@ -84,7 +134,10 @@ class TrainStepper:
         if self.fused:
             optim.device_state = True
         self.scale_dev = torch.ones(1, device=device) if scaler is not None else None
-        self.cur = _Cursor(dataset, batch_size, capacity, device)
+        self.host = host               # batches arrive from a DataLoader (host tensors) instead of being made on the device
+        self.cur = _Cursor(dataset, batch_size, capacity, device) if not host else None
+        self.feed = _HostFeed(device) if host else None
+        self.device = torch.device(device)
         self.graph, self.outs, self.eager_done = None, None, 0
         self._reduced = False
         # data-parallel: the step is captured as TWO graphs split where the gradients of the reconstruction head, the decoder and
@@ -103,8 +156,15 @@ class TrainStepper:
         return (self.n + self.batch - 1) // self.batch
 
     # ---- the step itself (what the slow loop of train_paired does, on device-made batches)
+    def _inputs(self, rows=None):
+        """(hr, lr) of the step being issued: made on the device from the next rows of the gather table, or the static buffers a
+        host batch was copied into."""
+        if self.host:
+            return self.feed.static if rows is None else rows
+        return self.dataset.device_batch(self.cur.next_rows() if rows is None else rows)
+
     def _fwd_bwd(self, rows):
-        hr, lr = self.dataset.device_batch(rows)
+        hr, lr = self._inputs(rows)
         hr_hat = self.model(lr)
         if self.clamp:
             hr_hat = torch.clamp(hr_hat, 0, self.image_range)
@@ -116,7 +176,7 @@ class TrainStepper:
         return hr, lr, hr_hat, loss
 
     def _body(self, rows=None):
-        out = self._fwd_bwd(self.cur.next_rows() if rows is None else rows)
+        out = self._fwd_bwd(rows)
         if self.in_graph_optim:
             self.optim.step()
             self.optim.zero_grad()      # Python only (.grad = None): the next backward publishes views of the flat buffer again
@@ -144,17 +204,30 @@ class TrainStepper:
             opt.step()
         opt.zero_grad()
 
-    def step(self):
-        """Next batch of the epoch.  Returns (hr, lr, hr_hat, loss) device tensors (static buffers once the graph is captured)."""
-        left = self.n - self.pos
-        if left < self.batch:                               # partial last batch: ordinary launches, its own engine plan
-            self._leave_graph()
-            out = self._body(self.cur.tail_rows(self.pos, left))
-            self._after()
-            self.pos += left
-            self._leave_graph()
-            return out
-        self.pos += self.batch
+    def step(self, batch=None):
+        """Next batch of the epoch (``batch``: the DataLoader's (hr, lr) host tensors in host mode).  Returns (hr, lr, hr_hat, loss)
+        device tensors (static buffers once the graph is captured)."""
+        if self.host:
+            hr, lr = (t if t.dtype == torch.float32 else t.float() for t in batch)
+            if self.feed.static is None and hr.shape[0] == self.batch:
+                self.feed.allocate((hr, lr))
+            if hr.shape[0] != self.batch or not self.feed.matches((hr, lr)):      # partial last batch / another tile size: ordinary launches
+                self._leave_graph()
+                out = self._body((hr.to(self.device), lr.to(self.device)))
+                self._after()
+                self._leave_graph()
+                return out
+            self.feed.push((hr, lr))
+        else:
+            left = self.n - self.pos
+            if left < self.batch:                               # partial last batch: ordinary launches, its own engine plan
+                self._leave_graph()
+                out = self._body(self.cur.tail_rows(self.pos, left))
+                self._after()
+                self.pos += left
+                self._leave_graph()
+                return out
+            self.pos += self.batch
         if self.graph is None and self.eager_done < self.WARM:
             if self.scaler is not None:
                 self.scale_dev.fill_(self.scaler.scale_value)
@@ -182,7 +255,11 @@ class TrainStepper:
                     torch.cuda.synchronize()
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                kw = {}
+                if os.environ.get("PSSR_GRAPH_PRIO", "0") == "2":       # experiment: capture on a high-priority stream too
+                    self._hi = torch.cuda.Stream(self.device, priority=-1)
+                    kw["stream"] = self._hi
+                with torch.cuda.graph(g, **kw):
                     self.outs = self._body()
                 self.graph = g
         if self.graph2 is not None:
@@ -200,9 +277,24 @@ class TrainStepper:
                 self.comm_events.append((ea, eb))
             self._reduced = True
         else:
-            self.graph.replay()
+            self._replay(self.graph)
         self._after()
         return self.outs
+
+    def _replay(self, graph):
+        """Replay on a HIGH-priority stream (PSSR_GRAPH_PRIO=0: on the current stream): the graph's dependent chain stays on the launch
+        stream's hardware queue while the forked weight-gradient branch runs on one of the executor's own (normal-priority) queues, so
+        the dispatcher hands free compute units to the chain first and the weight gradients fill what it leaves."""
+        if not _GRAPH_PRIO:
+            graph.replay()
+            return
+        if getattr(self, "_hi", None) is None:
+            self._hi = torch.cuda.Stream(self.engine._flat_grad.device, priority=-1)
+        cur = torch.cuda.current_stream()
+        self._hi.wait_stream(cur)
+        with torch.cuda.stream(self._hi):
+            graph.replay()
+        cur.wait_stream(self._hi)
 
     def _capture_split(self):
         """forward + loss + the first part of the backward | the rest of the backward, as two hipGraphs sharing one memory pool.  The
@@ -223,7 +315,7 @@ class TrainStepper:
             try:
                 g1.capture_begin(pool=pool)
                 state["g"] = g1
-                hr, lr = self.dataset.device_batch(self.cur.next_rows())
+                hr, lr = self._inputs()
                 raw = self.model(lr)
                 hr_hat = torch.clamp(raw, 0, self.image_range) if self.clamp else raw     # (the engine gets d loss / d raw: through the clamp)
                 loss = self.loss_fn(hr_hat / self.image_range, hr / self.image_range)
@@ -264,14 +356,16 @@ class EvalStepper:
     """No-grad forward (+ loss) over device-made batches as a replayed graph: the validation loop of ``train_paired``
     (pssr/train.py:122-148) and the prediction loop of ``predict_images`` (pssr/predict.py:52-60)."""
 
-    def __init__(self, model, dataset, batch_size, device, loss_fn=None, clamp=False, image_range=255, to_u8=False, weights_move=True):
+    def __init__(self, model, dataset, batch_size, device, loss_fn=None, clamp=False, image_range=255, to_u8=False, weights_move=True, host=False):
         self.model, self.dataset, self.batch, self.loss_fn = model, dataset, batch_size, loss_fn
+        self.host, self.device = host, torch.device(device)
+        self.feed = _HostFeed(device) if host else None
         self.clamp, self.image_range, self.to_u8 = clamp, image_range, to_u8
         self.engine = model._engine
         self.weights_move = weights_move           # True: the weights change between uses (validation inside training)
         # any order the drivers may ask for (validation split, a val_idx enlarged later to predict every image) fits a table of
         # len(dataset) rows
-        self.cur = _Cursor(dataset, batch_size, max(len(dataset), len(dataset.val_idx), batch_size), device)
+        self.cur = _Cursor(dataset, batch_size, max(len(dataset), len(dataset.val_idx), batch_size), device) if not host else None
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.graph, self.outs, self.eager_done = None, None, 0
         self.sig = None
@@ -282,22 +376,27 @@ class EvalStepper:
         m = self.model
         return (self.engine._wepoch[0], tuple(p._version for p in m.parameters()), tuple(b._version for b in m.buffers()))
 
-    def begin(self, order):
-        self.n = self.cur.load(order)
-        self.pos = 0
+    def begin(self, order=None):
+        if not self.host:
+            self.n = self.cur.load(order)
+            self.pos = 0
         self.loss_sum.zero_()
         self.count = 0
         if self.weights_move:
             self.engine.mark_weights_changed()
         elif self._signature() != self.sig:
             self.eager_done = 0             # the first full batch of this pass runs eagerly: packed weights / folded BatchNorm are refreshed
-        return (self.n + self.batch - 1) // self.batch
+        return (self.n + self.batch - 1) // self.batch if not self.host else None
 
     def _run(self, rows):
         from . import ops
         with torch.no_grad():
-            item = self.dataset.device_batch(rows)
-            hr, lr = (None, item) if self.dataset.is_lr else item
+            if self.host:
+                item = self.feed.static if rows is None else rows
+                hr, lr = (None, item[0]) if len(item) == 1 else item
+            else:
+                item = self.dataset.device_batch(self.cur.next_rows() if rows is None else rows)
+                hr, lr = (None, item) if self.dataset.is_lr else item
             hr_hat = self.model(lr)
             if self.clamp:
                 hr_hat = torch.clamp(hr_hat, 0, self.image_range)
@@ -312,20 +411,32 @@ class EvalStepper:
                 ops.clip_u8(y, u8)
         return hr, lr, hr_hat, loss, u8
 
-    def step(self):
-        left = self.n - self.pos
-        if left < self.batch:
-            if self.weights_move:
-                self.engine.mark_weights_changed()
-            out = self._run(self.cur.tail_rows(self.pos, left))
-            self.pos += left
+    def step(self, batch=None):
+        """``batch`` (host mode): the DataLoader's item -- (hr, lr) host tensors, or (lr,) for an LR-only dataset."""
+        if self.host:
+            batch = tuple(t if t.dtype == torch.float32 else t.float() for t in batch)
+            if self.feed.static is None and batch[-1].shape[0] == self.batch:
+                self.feed.allocate(batch)
             self.count += 1
-            return out
-        self.pos += self.batch
-        self.count += 1
+            if batch[-1].shape[0] != self.batch or not self.feed.matches(batch):
+                if self.weights_move:
+                    self.engine.mark_weights_changed()
+                return self._run(tuple(t.to(self.device) for t in batch))
+            self.feed.push(batch)
+        else:
+            left = self.n - self.pos
+            if left < self.batch:
+                if self.weights_move:
+                    self.engine.mark_weights_changed()
+                out = self._run(self.cur.tail_rows(self.pos, left))
+                self.pos += left
+                self.count += 1
+                return out
+            self.pos += self.batch
+            self.count += 1
         if self.eager_done < 1:
             self.eager_done += 1
-            out = self._run(self.cur.next_rows())
+            out = self._run(None)
             self.sig = self._signature()
             return out
         if self.graph is None:
@@ -334,7 +445,7 @@ class EvalStepper:
                 self.engine.mark_weights_changed()          # capture the packed-weight refresh and the BatchNorm folds too
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.outs = self._run(self.cur.next_rows())
+                self.outs = self._run(None)
             self.graph = g
         self.graph.replay()
         return self.outs

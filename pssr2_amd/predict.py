@@ -67,8 +67,20 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
     # (an extension of such datasets) keeps the uint8 predictions in HBM: the dict then holds device tensors
     from . import fastpath
     fast = fastpath.supports(model, dataset, device) and not dataloader_kwargs and len(idx) > 0
+    host_fast = not fast and fastpath.supports_host(model, dataset, device) and len(idx) > 0
     keep_dev = bool(getattr(dataset, "device_outputs", False)) and not out_dir and not norm
-    if fast:
+    if host_fast:
+        # host batches (any dataset through a DataLoader): one captured forward over a static input buffer per (dataset, batch size)
+        cache = model._engine.__dict__.setdefault("_eval_steppers", {})
+        evaler = cache.get((id(dataset), batch_size, "host"))
+        if evaler is None or evaler.dataset is not dataset:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            evaler = cache[(id(dataset), batch_size, "host")] = fastpath.EvalStepper(model, dataset, batch_size, device, to_u8=True, weights_move=False,
+                                                                                     host=True)
+        evaler.begin()
+        dataloader = DataLoader(dataset, batch_size, sampler=idx, **dataloader_kwargs)
+    elif fast:
         # one stepper (and one captured graph) per (dataset, batch size): a second call over the same dataset only replays
         cache = model._engine.__dict__.setdefault("_eval_steppers", {})
         evaler = cache.get((id(dataset), batch_size))
@@ -82,8 +94,8 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
     outs, cur_idx = {}, first
     with torch.no_grad():
         for item in tqdm(dataloader, disable=rank != 0):
-            if fast:
-                hr_dev, lr, _, _, u8 = evaler.step()
+            if fast or host_fast:
+                hr_dev, lr, _, _, u8 = evaler.step() if fast else evaler.step((item,) if dataset.is_lr else tuple(item))
                 hr_hat = u8.clone() if keep_dev else _slice_center(u8.cpu().numpy(), 1)      # u8 is the graph's static output buffer
             else:
                 lr = item if dataset.is_lr else item[1]
@@ -91,7 +103,7 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
                 hr_hat = _pred_array(model(lr))
             if norm:      # pssr/predict.py:63-64: intensities matched to the ground truth of the paired dataset
                 from .util import normalize_preds
-                _, hr_hat = normalize_preds(_pred_array(hr_dev if fast else item[0].to(device)), hr_hat)
+                _, hr_hat = normalize_preds(_pred_array(hr_dev if (fast or host_fast) else item[0].to(device)), hr_hat)
             crop_res = dataset.crop_res if not dataset.is_lr else dataset.crop_res * (hr_hat.shape[-1] // lr.shape[-1])
             hr_hat = hr_hat[:, :, :crop_res, :crop_res]
             for batch_idx, image_idx in enumerate(range(cur_idx, min(cur_idx + batch_size, first + len(idx)))):

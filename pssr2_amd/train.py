@@ -65,6 +65,9 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
     # (host datasets, DataLoader workers, user crappifier subclasses, ``extra`` losses) takes the reference's loop below
     from . import fastpath
     fast = fastpath.supports(model, dataset, device) and not dataloader_kwargs
+    # host datasets (the reference's own ImageDataset / SlidingDataset through a DataLoader, workers and all): the same replay over
+    # static input buffers, fed by one asynchronous host-to-device copy per batch
+    host_fast = not fast and fastpath.supports_host(model, dataset, device)
     if fast:
         train_dataloader = val_dataloader = None
     else:
@@ -72,7 +75,7 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
         val_dataloader = DataLoader(dataset, batch_size, sampler=val_sampler, **dataloader_kwargs)
     if world > 1:
         D.broadcast_module(model)
-        if engine is not None and engine.reducer is None and not fast:
+        if engine is not None and engine.reducer is None and not fast and not host_fast:
             engine.attach_reducer()
 
     # fp16 storage (model.compute_dtype = torch.float16) needs loss scaling; f32 / bf16 do not
@@ -85,6 +88,9 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
     if fast:
         stepper = fastpath.TrainStepper(model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, len(train_sampler), device)
         evaler = fastpath.EvalStepper(model, dataset, batch_size, device, loss_fn=loss_fn, clamp=clamp, image_range=image_range)
+    elif host_fast:
+        stepper = fastpath.TrainStepper(model, dataset, batch_size, loss_fn, optim, clamp, image_range, scaler, 0, device, host=True)
+        evaler = fastpath.EvalStepper(model, dataset, batch_size, device, loss_fn=loss_fn, clamp=clamp, image_range=image_range, host=True)
 
     train_losses, val_losses = [], []
     # world > 1: an exception on one rank (a callback's, say) ends every rank within seconds (pssr2_amd/distributed.py: failure_watch)
@@ -100,6 +106,8 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
             for batch_idx, data in enumerate(progress):
                 if fast:
                     hr, lr, hr_hat, loss = stepper.step()
+                elif host_fast:
+                    hr, lr, hr_hat, loss = stepper.step(data)
                 else:
                     if dataset.extra_hr_files is None:
                         hr, lr = data
@@ -132,7 +140,7 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
                     last_full = [lr.cpu(), hr_hat.detach().cpu(), hr.cpu()]       # accessible from callbacks via locals
                 for idx, callback in enumerate(callbacks):
                     callback(locals()) if callback_locals[idx] else callback()
-            if fast:
+            if fast or host_fast:
                 stepper.finish()
 
             model.eval()
@@ -142,11 +150,15 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
             if fast:
                 progress = tqdm(range(evaler.begin(list(val_sampler))), disable=rank != 0)
             else:
+                if host_fast:
+                    evaler.begin()
                 progress = tqdm(val_dataloader, disable=rank != 0)
             with torch.no_grad():
                 for batch_idx, data in enumerate(progress):
                     if fast:
                         hr, lr, hr_hat, loss, _ = evaler.step()
+                    elif host_fast:
+                        hr, lr, hr_hat, loss, _ = evaler.step(tuple(data))
                     else:
                         if dataset.extra_hr_files is None:
                             hr, lr = data
@@ -162,7 +174,7 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
                         val_loss.append(loss.detach().float().reshape(1))            # stays on device: one sync per epoch
                     if batch_idx == max(len(progress), 2) - 2:
                         last_full_val = [lr.cpu(), hr_hat.cpu(), hr.cpu()]
-            if fast:
+            if fast or host_fast:
                 stat = evaler.mean_loss_stat()
                 engine.mark_weights_changed()
             else:

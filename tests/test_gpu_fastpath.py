@@ -184,3 +184,85 @@ def test_empty_validation_split_and_enlarged_val_idx():
     ds.val_idx = list(range(len(ds)))
     b = predict_images(model, ds, device="cuda", batch_size=2, out_dir=None)
     assert len(b) == 32 and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def _run_train_host(host_graph, fused, pin):
+    """train_paired on a HOST dataset (ArrayDataset: Pillow reduction + numpy crappifier on the CPU, through a DataLoader)."""
+    from pssr2_amd import fastpath as FP
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import ArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    os.environ["PSSR_HOST_GRAPH"] = "1" if host_graph else "0"
+    try:
+        torch.manual_seed(3)
+        random.seed(11)
+        np.random.seed(5)
+        model = ResUNet(hidden=[16, 32], depth=1).cuda()
+        model.compute_dtype = torch.float32
+        ds = ArrayDataset(_tiles(44, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.2, rotation=True)
+        assert FP.supports_host(model, ds, "cuda") == host_graph and not FP.supports(model, ds, "cuda")
+        opt = (FusedAdamW if fused else torch.optim.AdamW)(model.parameters(), lr=2e-3, eps=1e-3)
+        seen = []
+
+        def cb(loc):
+            seen.append((loc["batch_idx"], tuple(loc["hr_hat"].shape), float(loc["loss"].detach()), float(loc["hr"].sum()), float(loc["lr"].sum())))
+        FP.LAST_TRAIN_STEPPER = None
+        tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 2, device="cuda", log_frequency=2, callbacks=[cb],
+                              dataloader_kwargs=dict(pin_memory=True) if pin else None)
+        stp = FP.LAST_TRAIN_STEPPER
+        assert (stp is not None and stp.host and stp.graph is not None) == host_graph
+        return tl, vl, {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, seen
+    finally:
+        os.environ.pop("PSSR_HOST_GRAPH", None)
+
+
+@pytest.mark.parametrize("fused,pin", [(True, True), (False, False)], ids=["FusedAdamW-pinned", "torch-AdamW-pageable"])
+def test_train_paired_host_dataset_graph_equals_eager(fused, pin):
+    """the reference's own kind of dataset (host tensors out of a DataLoader) takes a replayed graph too -- static
+    input buffers, one asynchronous host-to-device copy per batch -- and gives what the launch-by-launch loop gives on the same batches
+    (36 training tiles in batches of 8: 2 eager, 1 captured, 1 replayed, then a partial batch of 4; 8 validation tiles; 2 epochs)."""
+    a = _run_train_host(True, fused, pin)
+    b = _run_train_host(False, fused, pin)
+    assert len(a[0]) == len(b[0]) and len(a[1]) == len(b[1]) == 2
+    assert [s[:2] for s in a[3]] == [s[:2] for s in b[3]] and len(a[3]) == 10 and a[3][4][1][0] == 4
+    assert [s[3:] for s in a[3]] == [s[3:] for s in b[3]]                 # the same batches reached the device in the same order
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-5)
+    np.testing.assert_allclose([s[2] for s in a[3]], [s[2] for s in b[3]], rtol=2e-5)
+    for k in a[2]:
+        if "num_batches_tracked" in k:
+            assert int(a[2][k]) == int(b[2][k]) == 10
+            continue
+        parts = k.split(".")
+        if parts[-1] == "bias" and "conv" in parts and parts[parts.index("conv") + 1] in ("0", "3"):
+            continue
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_predict_images_host_dataset_graph_equals_eager():
+    """predict_images over a host dataset in LR mode (SlidingArrayDataset: the c5 shape of input) and over a paired host dataset:
+    the replayed forward gives the eager loop's uint8 predictions bit for bit, partial last batch included."""
+    from pssr2_amd.data import ArrayDataset, SlidingArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images
+    torch.manual_seed(4)
+    model = ResUNet(hidden=[16, 32], depth=1).cuda()
+    model.compute_dtype = torch.bfloat16
+    rng = np.random.default_rng(1)
+    sheet = rng.integers(0, 256, size=(1, 100, 132), dtype=np.uint8)
+    dss = [SlidingArrayDataset([sheet], hr_res=32, overlap=8), ArrayDataset(_tiles(11, 64, seed=2), hr_res=64, lr_scale=4, crappifier=None, val_split=1.0, rotation=False)]
+    for ds in dss:
+        os.environ["PSSR_HOST_GRAPH"] = "0"
+        try:
+            ref = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None)
+        finally:
+            os.environ.pop("PSSR_HOST_GRAPH", None)
+        got = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None)
+        again = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None)
+        assert list(got) == list(ref) and len(ref) == len(ds.val_idx) and len(ref) % 4 != 0
+        for k in ref:
+            assert got[k].dtype == np.uint8 and np.array_equal(got[k], ref[k]) and np.array_equal(again[k], ref[k]), k
+    assert any(key[-1] == "host" for key in model._engine._eval_steppers)
