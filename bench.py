@@ -614,6 +614,8 @@ def main():
             del model_h, hds
         except Exception as e:                                     # an extra leg must not take the headline line with it
             res["extras_error"] = f"{type(e).__name__}: {e}"
+            import traceback
+            traceback.print_exc(file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "resunet":
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

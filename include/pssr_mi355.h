@@ -565,6 +565,16 @@ typedef struct pssr_copy_batch {
     int64_t n[PSSR_COPY_BATCH_MAX];
 } pssr_copy_batch;
 int pssr_copy_f32_batch(const pssr_copy_batch* items, int n_items, pssr_stream_t stream);
+/* Several pssr_f64_to_f32 folds (striped f64 statistic rows [stripes][n] -> f32 [n], optionally accumulated) by one launch: the
+ * bias / LayerNorm / layer-scale gradient sums of a backward pass (RDNet has ~115 per step) are parameter gradients nobody reads
+ * before the pass ends, so the engine queues them and folds 16 at a time. */
+typedef struct pssr_fold_batch {
+    float* dst[PSSR_COPY_BATCH_MAX];
+    const double* src[PSSR_COPY_BATCH_MAX];
+    int32_t n[PSSR_COPY_BATCH_MAX];
+    int32_t accumulate[PSSR_COPY_BATCH_MAX];
+} pssr_fold_batch;
+int pssr_f64_to_f32_batch(const pssr_fold_batch* items, int n_items, int stripes, pssr_stream_t stream);
 
 #ifdef __cplusplus
 }

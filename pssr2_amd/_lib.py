@@ -61,6 +61,11 @@ class GatherItem(C.Structure):
 COPY_BATCH_MAX = 16
 
 
+class FoldBatch(C.Structure):
+    """struct pssr_fold_batch"""
+    _fields_ = [("dst", C.c_void_p * 16), ("src", C.c_void_p * 16), ("n", C.c_int32 * 16), ("accumulate", C.c_int32 * 16)]
+
+
 class CopyBatch(C.Structure):
     """struct pssr_copy_batch (include/pssr_mi355.h)."""
     _fields_ = [("dst", C.c_void_p * COPY_BATCH_MAX), ("src", C.c_void_p * COPY_BATCH_MAX), ("n", C.c_int64 * COPY_BATCH_MAX)]

@@ -84,11 +84,7 @@ template <int BN> struct Cfg3 {
     V3_MM(OP, 0, 8, 12) V3_MM(OP, 1, 8, 13) V3_MM(OP, 2, 9, 12) V3_MM(OP, 3, 9, 13)          \
     V3_MM(OP, 4, 10, 12) V3_MM(OP, 5, 10, 13) V3_MM(OP, 6, 11, 12) V3_MM(OP, 7, 11, 13)
 #define V3_WAIT "s_waitcnt lgkmcnt(0)\n\t"
-#ifdef PSSR_V3_SETPRIO      // experiment: the multiplying wave outranks its SIMD partner (the other workgroup's wave) in instruction arbitration
-#define V3_ROW_TEXT(OP) V3_READ0(0, 0) V3_WAIT "s_setprio 1\n\t" V3_TAP01(OP, 1) V3_WAIT V3_TAP10(OP, 2) V3_WAIT V3_TAP0_LAST(OP) "s_setprio 0\n\t"
-#else
 #define V3_ROW_TEXT(OP) V3_READ0(0, 0) V3_WAIT V3_TAP01(OP, 1) V3_WAIT V3_TAP10(OP, 2) V3_WAIT V3_TAP0_LAST(OP)
-#endif
 #define V3_ONE_TEXT(OP) V3_READ0(1, 0) V3_WAIT V3_TAP0_LAST(OP)
 #define V3_OPERANDS(AOFF, BOFF)                                                                                           \
         : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),           \

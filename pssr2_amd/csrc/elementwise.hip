@@ -533,6 +533,20 @@ __global__ void f64_to_f32_kernel(const double* in, float* out, int n, int accum
     out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
+// several folds by one launch (blockIdx.y = item): RDNet's backward pass ends ~115 bias / LayerNorm gradient sums per step this way
+__global__ void f64_to_f32_batch_kernel(pssr_fold_batch items, int stripes) {
+    const int it = blockIdx.y;
+    const int n = items.n[it];
+    if ((int)(blockIdx.x * STRIPE_CH) >= n) return;          // (uniform per workgroup)
+    const int i = blockIdx.x * STRIPE_CH + threadIdx.x;
+    const long off[1] = {i};
+    double sv[1];
+    stripe_sums<1>(items.src[it], (long)n, off, stripes, i < n, sv);
+    if (i >= n || threadIdx.y != 0) return;
+    float* out = items.dst[it];
+    out[i] = items.accumulate[it] ? out[i] + (float)sv[0] : (float)sv[0];
+}
+
 static inline int grid1d(long total) { long b = (total + TPB - 1) / TPB; return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
 
 }  // namespace
@@ -754,6 +768,18 @@ int pssr_clip_u8(const float* in, uint8_t* out, int64_t n, pssr_stream_t s) {
 int pssr_f64_to_f32(const double* in, float* out, int n, int accumulate, int stripes, pssr_stream_t s) {
     PSSR_CHECK(in && out && n > 0 && stripes > 0, PSSR_ERR_ARG, "f64_to_f32: bad args");
     hipLaunchKernelGGL(f64_to_f32_kernel, dim3(cdiv(n, STRIPE_CH)), dim3(STRIPE_CH, STRIPE_SG), 0, (hipStream_t)s, in, out, n, accumulate, stripes);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_f64_to_f32_batch(const pssr_fold_batch* items, int n_items, int stripes, pssr_stream_t s) {
+    PSSR_CHECK(items && n_items > 0 && n_items <= PSSR_COPY_BATCH_MAX && stripes > 0, PSSR_ERR_ARG, "f64_to_f32_batch: 1..%d items", PSSR_COPY_BATCH_MAX);
+    int longest = 0;
+    for (int i = 0; i < n_items; ++i) {
+        PSSR_CHECK(items->dst[i] && items->src[i] && items->n[i] > 0, PSSR_ERR_ARG, "f64_to_f32_batch: item %d is empty", i);
+        if (items->n[i] > longest) longest = items->n[i];
+    }
+    hipLaunchKernelGGL(f64_to_f32_batch_kernel, dim3(cdiv(longest, STRIPE_CH), n_items), dim3(STRIPE_CH, STRIPE_SG), 0, (hipStream_t)s, *items, stripes);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

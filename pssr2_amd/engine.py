@@ -185,9 +185,16 @@ class Engine:
         """Publish the gradients.  The engine owns the .grad of its parameters: a parameter without a gradient gets the
         view of the flat buffer itself (no AccumulateGrad copy, and FusedAdamW / the all-reduce see one flat tensor); an
         existing gradient is accumulated into, as autograd would."""
+        self._flush_folds()
         if self.reducer is not None:
             self.reducer.finish()
         self._side_join()
+        if getattr(self.model, "autograd_grads", False):
+            # model.autograd_grads = True: hand the gradients to autograd like any torch.autograd.Function does (copies out of the
+            # flat buffer, which the next backward pass overwrites) and leave .grad to it -- what torch.autograd.grad(loss, params),
+            # post-accumulate-grad hooks and third-party training loops built on them need.  Costs one copy of every gradient per
+            # step and loses the flat-buffer fast path of FusedAdamW; off by default.
+            return {id(prm): view.clone() for prm, view in zip(self.model.parameters(), self._gviews) if prm.requires_grad}
         with torch.no_grad():
             for prm, view in zip(self.model.parameters(), self._gviews):
                 if not prm.requires_grad:
@@ -262,6 +269,7 @@ class Engine:
         self._deferred = None
         self._pending = {}
         self._side_on = False
+        self.__dict__.get("_folds", []).clear()
 
     def _side_join(self):
         if self._side_on:
@@ -271,8 +279,20 @@ class Engine:
             torch.cuda.current_stream().wait_event(ev)
             self._pending = {}
 
+    def _fold(self, s64, dst):
+        """Queue ``ops.f64_to_f32(s64, dst)`` for the next _ready / the end of the pass (one launch per 16 folds).  Only for sums that
+        nothing on the device reads before then (parameter gradients) and that live in storage nothing reuses meanwhile."""
+        self.__dict__.setdefault("_folds", []).append((s64, dst, False))
+
+    def _flush_folds(self):
+        q = self.__dict__.get("_folds")
+        if q:
+            ops.f64_to_f32_batch(q)
+            q.clear()
+
     def _ready(self, grads, params):
         """Copy small side results into their slots and tell the reducer these parameters are final."""
+        self._flush_folds()
         if self._side_on:
             self._flush_side()
         idx, moves = [], []

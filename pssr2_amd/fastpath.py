@@ -24,7 +24,9 @@ from . import distributed as D
 from .util import SSIMLoss as _SSIMLoss
 
 
-_GRAPH_PRIO = os.environ.get("PSSR_GRAPH_PRIO", "0") != "0"
+# stream capture in thread-local mode: a DataLoader's pin-memory thread allocates pinned host memory while the main thread captures
+# (in the default global mode any such call from ANY thread invalidates the capture)
+_CAPTURE_MODE = "thread_local"
 LAST_TRAIN_STEPPER = None      # the stepper of the most recent train_paired call (bench.py reads its communication statistics)
 
 
@@ -52,6 +54,35 @@ def supports_host(model, dataset, device):
         return False
     return (enabled() and os.environ.get("PSSR_HOST_GRAPH", "1") != "0" and getattr(model, "_engine", None) is not None
             and torch.device(device).type == "cuda" and getattr(dataset, "extra_hr_files", None) is None)
+
+
+class _capture:
+    """``torch.cuda.graph`` with the collector switched off for the duration: the backward pass of a captured step runs on autograd's
+    worker thread, and a collection there that happens to free an older captured graph (its private memory pool) while THIS capture is
+    under way asserts inside torch's allocator and takes the process down (seen when a failed test had left steppers behind)."""
+
+    def __init__(self, graph):
+        self.ctx = torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE)
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was_on:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_on:
+                gc.enable()
 
 
 class _HostFeed:
@@ -255,11 +286,7 @@ class TrainStepper:
                     torch.cuda.synchronize()
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
-                kw = {}
-                if os.environ.get("PSSR_GRAPH_PRIO", "0") == "2":       # experiment: capture on a high-priority stream too
-                    self._hi = torch.cuda.Stream(self.device, priority=-1)
-                    kw["stream"] = self._hi
-                with torch.cuda.graph(g, **kw):
+                with _capture(g):
                     self.outs = self._body()
                 self.graph = g
         if self.graph2 is not None:
@@ -277,24 +304,9 @@ class TrainStepper:
                 self.comm_events.append((ea, eb))
             self._reduced = True
         else:
-            self._replay(self.graph)
+            self.graph.replay()
         self._after()
         return self.outs
-
-    def _replay(self, graph):
-        """Replay on a HIGH-priority stream (PSSR_GRAPH_PRIO=0: on the current stream): the graph's dependent chain stays on the launch
-        stream's hardware queue while the forked weight-gradient branch runs on one of the executor's own (normal-priority) queues, so
-        the dispatcher hands free compute units to the chain first and the weight gradients fill what it leaves."""
-        if not _GRAPH_PRIO:
-            graph.replay()
-            return
-        if getattr(self, "_hi", None) is None:
-            self._hi = torch.cuda.Stream(self.engine._flat_grad.device, priority=-1)
-        cur = torch.cuda.current_stream()
-        self._hi.wait_stream(cur)
-        with torch.cuda.stream(self._hi):
-            graph.replay()
-        cur.wait_stream(self._hi)
 
     def _capture_split(self):
         """forward + loss + the first part of the backward | the rest of the backward, as two hipGraphs sharing one memory pool.  The
@@ -309,11 +321,15 @@ class TrainStepper:
         def switch():
             g1.capture_end()
             state["g"] = None
-            g2.capture_begin(pool=pool)
+            g2.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
             state["g"] = g2
+        import gc
+        gc.collect()
+        gc_on = gc.isenabled()
+        gc.disable()
         with torch.cuda.stream(cap):
             try:
-                g1.capture_begin(pool=pool)
+                g1.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
                 state["g"] = g1
                 hr, lr = self._inputs()
                 raw = self.model(lr)
@@ -332,6 +348,9 @@ class TrainStepper:
                     except Exception:
                         pass
                 raise
+            finally:
+                if gc_on:
+                    gc.enable()
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.graph, self.graph2, self.split_at = g1, g2, eng.grad_split_offset()
@@ -444,7 +463,7 @@ class EvalStepper:
             if self.weights_move:
                 self.engine.mark_weights_changed()          # capture the packed-weight refresh and the BatchNorm folds too
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 self.outs = self._run(None)
             self.graph = g
         self.graph.replay()

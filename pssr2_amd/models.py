@@ -156,6 +156,7 @@ class ResUNet(nn.Module):
         self.channels, self.hidden, self.depth = channels, hidden, depth
         self.compute_dtype = torch.float32
         self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
+        self.autograd_grads = False   # True: return parameter gradients to autograd (torch.autograd.grad, gradient hooks) instead of publishing .grad
         self._engine = Engine(self)
 
     def forward(self, x):
@@ -338,6 +339,7 @@ class RDResUNet(nn.Module):
         self.channels, self.hidden, self.depth = channels, hidden, depth
         self.compute_dtype = torch.float32
         self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
+        self.autograd_grads = False   # True: return parameter gradients to autograd (torch.autograd.grad, gradient hooks) instead of publishing .grad
         from .rd_engine import RDEngine
         self._engine = RDEngine(self)
 

@@ -222,6 +222,18 @@ def f64_to_f32(src, dst, accumulate=False, stripes=STAT_STRIPES):
     L.check(L.lib().pssr_f64_to_f32(L.ptr(src), L.ptr(dst), dst.numel(), int(accumulate), stripes, L.stream_ptr()), "pssr_f64_to_f32")
 
 
+def f64_to_f32_batch(items, stripes=STAT_STRIPES):
+    """[(src f64 [stripes * n], dst f32 [n], accumulate), ...] folded by one launch per 16 items (pssr_f64_to_f32_batch)."""
+    for k in range(0, len(items), L.COPY_BATCH_MAX):
+        chunk = items[k:k + L.COPY_BATCH_MAX]
+        fb = L.FoldBatch()
+        for i, (src, dst, acc) in enumerate(chunk):
+            if src.dtype != torch.float64 or dst.dtype != torch.float32 or src.numel() < stripes * dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+                raise ValueError("f64_to_f32_batch needs contiguous float64 [stripes * n] sources and float32 [n] destinations")
+            fb.dst[i], fb.src[i], fb.n[i], fb.accumulate[i] = dst.data_ptr(), src.data_ptr(), dst.numel(), int(acc)
+        L.check(L.lib().pssr_f64_to_f32_batch(C.byref(fb), len(chunk), stripes, L.stream_ptr()), "pssr_f64_to_f32_batch")
+
+
 # ----------------------------------------------------------------------------------------------
 # loss + optimizer (csrc/loss.hip, csrc/optim.hip)
 def _win(win):

@@ -47,6 +47,11 @@ class _ZeroArena:
             self.buf.zero_()
         self.pos = self.asked = 0
 
+    def owns(self, t):
+        """t is a slice of the arena (unique for the rest of the pass), not a reused fallback buffer."""
+        b = self.buf
+        return b is not None and b.data_ptr() <= t.data_ptr() < b.data_ptr() + b.numel() * b.element_size()
+
     def take(self, n, fallback):
         """n zeroed elements: a slice of the arena, or (first pass / grown need) ``fallback`` zeroed in place."""
         n_al = (n + 3) // 4 * 4
@@ -301,15 +306,22 @@ class RDEngine(Engine):
             gb = self._flat_grad[self._goffs[iw]:self._goffs[iw] + 2 * c]
         else:
             gb = torch.empty(2 * c, dtype=torch.float32, device=bw.stat_ln.device)
-        ops.f64_to_f32(s64, gb)
+        self._fold64(s64, gb)
         grads[id(ln_module.weight)], grads[id(ln_module.bias)] = gb[:c], gb[c:]
+
+    def _fold64(self, s64, dst):
+        """Striped f64 sums -> f32 parameter gradient: queued for one batched launch (Engine._fold) when the sums sit in the arena."""
+        if self._z64 is not None and self._z64.owns(s64):
+            self._fold(s64, dst)
+        else:
+            ops.f64_to_f32(s64, dst)
 
     def _bias_grad(self, bw, grads, bias, t, npix, c, code, coff=0):
         """d bias = per-channel sum of the output gradient (f64 striped accumulation)."""
         s64 = self._z64.take(ops.STAT_STRIPES * c, bw.stat_ln)
         ops.channel_sum_nhwc(t, npix, c, s64, code, coff=coff)
         g = self._gbuf(bias)               # straight into the parameter's slot of the flat gradient buffer
-        ops.f64_to_f32(s64, g)
+        self._fold64(s64, g)
         grads[id(bias)] = g
 
     def _wgrad1x1(self, p, grads, conv_module, dy, cout, dy_coff, src, cin_pad, hh, ww, *, mode=0, gelu_in=False):
@@ -442,7 +454,7 @@ class RDEngine(Engine):
         ops.conv2d(sc.dt, sc.dt.shape[-1], self._pw(c2, "dgrad", code, mode=1), sc.dz, bk.inter, n=n, h=st.h, w=st.w,
                    epilogue=L.EPI_DGRAD_GELU, flags=L.FLAG_STATS, aux=bk.z, stats=s64)
         sums = torch.empty(2 * bk.inter, dtype=torch.float32, device=G.device)
-        ops.f64_to_f32(s64, sums)
+        self._fold64(s64, sums)
         grads[id(c1.bias)] = sums[:bk.inter]
         # ---- first 1x1 conv (input = LayerNorm output)
         cpad = bk.ln.shape[-1]

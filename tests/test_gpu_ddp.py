@@ -70,7 +70,8 @@ def test_callback_exception_on_one_rank_ends_all_ranks():
                 p.kill()
     assert all(p.returncode not in (0, None) for p in procs), [(p.returncode, o[-800:]) for p, o in zip(procs, outs)]
     assert "callback failed on rank 1" in outs[1]
-    assert "leaving train_paired" in outs[0], outs[0][-800:]
+    # rank 0 leaves through the watch thread, or -- when rank 1's exit closes the gloo connection first -- through the failed collective
+    assert "leaving train_paired" in outs[0] or "Connection closed by peer" in outs[0], outs[0][-800:]
     assert time.time() - t0 < 170
 
 

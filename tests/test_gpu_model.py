@@ -309,3 +309,29 @@ def test_eval_batchnorm_folding_tracks_parameters_and_training():
     model(x.cuda())                                                                 # training forward: running statistics updated by the kernels
     model.eval()
     check(model, model.state_dict())
+
+
+def test_autograd_grad_and_hooks_when_asked(golden):
+    """DESIGN.md section 2: by default the engine publishes ``.grad`` itself (views of its flat buffer) and autograd receives nothing;
+    ``model.autograd_grads = True`` returns the gradients through autograd instead, so ``torch.autograd.grad(loss, params)`` and
+    post-accumulate-grad hooks work as with the reference's plain nn.Module -- same values either way."""
+    g = golden("model.npz")
+    model, x = _load(g, "tiny")
+    model.train()
+    target = torch.tensor(g["tiny_target"]).cuda()
+    torch.nn.functional.mse_loss(model(x) / 255, target / 255).backward()
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model2, _ = _load(g, "tiny")
+    model2.train()
+    model2.autograd_grads = True
+    params = list(model2.parameters())
+    got = torch.autograd.grad(torch.nn.functional.mse_loss(model2(x) / 255, target / 255), params)
+    assert all(p.grad is None for p in params)                       # autograd.grad does not touch .grad
+    for (n, _), gr in zip(model2.named_parameters(), got):
+        assert torch.equal(gr, want[n]), n
+    seen = []
+    hook = params[3].register_post_accumulate_grad_hook(lambda p: seen.append(float(p.grad.abs().sum())))
+    torch.nn.functional.mse_loss(model2(x) / 255, target / 255).backward()
+    hook.remove()
+    assert len(seen) == 1 and seen[0] == float(want[list(dict(model2.named_parameters()))[3]].abs().sum())
+    assert torch.equal(params[0].grad, want[list(dict(model2.named_parameters()))[0]])
