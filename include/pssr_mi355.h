@@ -151,7 +151,7 @@ int pssr_conv2d_pipeline_mode(int mode);
  * from the environment variables PSSR_<NAME> on first use and changed afterwards only through pssr_set_option(); no launch
  * path reads the environment.  Names: IGEMM_V3 (1: LDS-DMA / counted-wait 3x3 loop for 16-bit layers with > 64 output
  * channels on >= 16x16 images when its 256-pixel tiles fill the chip; 2: whenever the shape allows; 0: the 128-pixel loop), IGEMM_FLAT, IGEMM_BIG, IGEMM_KSPLIT, CONV_EPI8, WGRAD_LEAN,
- * WGRAD_BLOCKS, WGRAD_BLOCKS_1X1, DWCONV_TILE, DWWG_BLOCKS.  pssr_set_option returns the previous value (>= 0) or PSSR_ERR_ARG
+ * WGRAD_DMA, WGRAD_BLOCKS, WGRAD_BLOCKS_1X1, DWCONV_TILE, DWWG_BLOCKS.  pssr_set_option returns the previous value (>= 0) or PSSR_ERR_ARG
  * for an unknown name / out-of-range value; pssr_get_option returns the value or PSSR_ERR_ARG. */
 int pssr_set_option(const char* name, int value);
 int pssr_get_option(const char* name);
@@ -198,6 +198,11 @@ int pssr_bn_finalize(const double* stats, double count, const float* gamma, cons
 int pssr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift, int c,
                         pssr_stream_t stream);
+/* a = relu(scale * y + shift) in the storage type (16-bit, power-of-two channel count): the activated input of the next convolution of a
+ * ResBlock (pssr/models/_blocks.py:26-41, nn.BatchNorm2d + nn.ReLU) written out once per layer, bit-identical to what the convolution
+ * loaders' BatchNorm+ReLU prologue stages, so that pssr_conv2d_wgrad can read it without a prologue (LDS-DMA kernel). */
+int pssr_bn_relu_apply(const void* y, int y_cs, int y_co, const float* scale, const float* shift, void* a, int a_cs,
+                       int a_co, int64_t npix, int c, int dtype, pssr_stream_t stream);
 /* BatchNorm backward: with stats = [sum g, sum g*xhat] the input gradient is A*g + B*y + C per channel;
  * also emits dgamma = sum g*xhat and dbeta = sum g (either may be NULL). */
 int pssr_bn_bwd_coefs(const double* stats, double count, const float* gamma, const float* mean,

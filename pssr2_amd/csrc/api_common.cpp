@@ -29,11 +29,13 @@ const Entry kEntries[] = {
     {"IGEMM_BIG", &PssrTunables::igemm_big, 1, 0, 2},
     {"IGEMM_V3", &PssrTunables::igemm_v3, 1, 0, 2},
     {"IGEMM_V3_64", &PssrTunables::igemm_v3_64, 1, 0, 1},
+    {"V3_LDS_PAD", &PssrTunables::v3_lds_pad, 0, 0, 100},
     {"IGEMM_DBG", &PssrTunables::igemm_dbg, 0, 0, 255},
     {"IGEMM_KSPLIT", &PssrTunables::igemm_ksplit, 384, 1, 1 << 20},
     {"CONV_EPI8", &PssrTunables::conv_epi8, 1, 0, 1},
     {"WGRAD_LEAN", &PssrTunables::wgrad_lean, 1, 0, 1},
     {"WGRAD_X2", &PssrTunables::wgrad_x2, 0, 0, 1},
+    {"WGRAD_DMA", &PssrTunables::wgrad_dma, 1, 0, 1},
     {"WGRAD_BLOCKS", &PssrTunables::wgrad_blocks, 256, 1, 1 << 20},
     {"WGRAD_BLOCKS_1X1", &PssrTunables::wgrad_blocks_1x1, 512, 1, 1 << 20},
     {"DWCONV_TILE", &PssrTunables::dwconv_tile, 1, 0, 1},

@@ -872,11 +872,15 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
     p.ksplit = ksplit;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + PRO_LDS_MAX);
+        (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_splitk_finish3_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds, stream, p);
+    // V3_LDS_PAD (KiB, experiment): unused LDS that keeps a second workgroup off the CU -- halves the input lines an XCD's L2 has to
+    // hold between the K chunks of a tile
+    int pad = pssr_tunables().v3_lds_pad * 1024;
+    if (C::LDS_BYTES + pro_lds + pad > 160 * 1024) pad = 160 * 1024 - C::LDS_BYTES - pro_lds;
+    hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds + pad, stream, p);
     if (ksplit > 1)
         hipLaunchKernelGGL((conv_splitk_finish3_kernel<T, BN>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
     PSSR_LAUNCH_CHECK();

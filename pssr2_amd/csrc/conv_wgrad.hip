@@ -519,6 +519,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// All-DMA build of the lean 3x3 kernel for a prologue-free input (round 3).  Phase stamps of conv_wgrad16_kernel per 128-pixel tile:
+// multiply 2580 clocks (72 MFMAs = 2304), commit 1830 (BatchNorm/ReLU prologue + ten ds_write_b128), issue 1140, barriers 400 -- the
+// matrix pipe works 38 % of a workgroup's life because every staged byte crosses the register file and the vector ALU.  When the
+// input needs no prologue (the engine materialises relu(bn(y)) once per layer, on the second stream under the forward pass:
+// Engine._materialise) BOTH operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: out-of-range offsets = zero fill = the
+// conv's zero padding and the channel tails), double-buffered: the 40 KiB of pixel tile i + 1 land while tile i is multiplied.  No
+// staging registers, no commit, ~10 vector instructions per tile per wave besides the MFMAs and their fragment reads.
+// LDS image per buffer: dy [CO_S][128 px][64 B] | input halo [CI_S][HPP px][64 B] (HPP = halo pixels rounded up to whole 16-pixel
+// pieces, an even number of them per sub-tile); a piece = one wave instruction = 16 pixels x 64 B of one 32-channel sub-tile = 1 KiB, lane l -> (pixel l / 4, 16 B l % 4).
+template <typename T, int CO_T, int CI_T, int GEO, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad16d_kernel(const WgradArgs p) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2 && GEO < 2, "16-bit types, tiles of at least 8x8 pixels");
+    constexpr int EPS = 8, ESZ = 2;
+    constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NI = 128 >> (TWL + THL);
+    constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI, HPP = (HP + 31) / 32 * 32;
+    constexpr int ROWB = 64;
+    constexpr int CO_S = CO_T / 32, CI_S = CI_T / 32;
+    static_assert(CO_S * CI_S == 4, "one (cout sub, cin sub) pair per wave");
+    constexpr int DY_BYTES = CO_S * 128 * ROWB, AH_BYTES = CI_S * HPP * ROWB, BUF = DY_BYTES + AH_BYTES;
+    constexpr int DY_PCS = DY_BYTES / 1024, AH_PCS = AH_BYTES / 1024, PCS = DY_PCS + AH_PCS;
+    static_assert(PCS % 4 == 0, "pieces per wave");
+    constexpr int PW = PCS / 4;                                           // pieces a wave issues per pixel tile
+    static_assert(PW <= 16, "class bits");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cosub = wave % CO_S, cisub = wave / CO_S;
+    const int ct = blockIdx.y;
+    const int n0 = (ct % p.co_tiles) * CO_T, k0 = (ct / p.co_tiles) * CI_T;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ---- tile-independent piece descriptors: piece q = wave + 4 j
+    unsigned voff[PW];                               // byte offset relative to the tile origin (+ WG_BIAS), or out of range
+    unsigned long long cls = 0;                      // 4 bits per piece: this lane's halo pixel lies on the left / right / top / bottom ring
+    const int lp = lane >> 2, pin = lane & 3;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int q = wave + 4 * j;
+        if (q < DY_PCS) {
+            const int sub = q / (128 / 16), m = (q % (128 / 16)) * 16 + lp;
+            const int tx = m & (TW - 1), ty = (m >> TWL) & (TH - 1), img = m >> (TWL + THL);
+            const int ch = n0 + sub * 32 + pin * EPS;
+            voff[j] = ch < p.cout ? (unsigned)(wg_rel_pix(img, ty, tx, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ + ch * ESZ) + WG_BIAS : 0xffffffffu;
+        } else {
+            const int qa = q - DY_PCS;
+            const int sub = qa / (HPP / 16), pp = (qa % (HPP / 16)) * 16 + lp;
+            const int img = pp / HPI, rem = pp % HPI;
+            const int hy = rem / HW2, hx = rem % HW2;
+            const int ch = k0 + sub * 32 + pin * EPS;
+            const bool live = pp < HP && ch < p.cin_pad;
+            voff[j] = live ? (unsigned)(wg_rel_pix(img, hy - 1, hx - 1, p.H, p.W, p.in_blk) * p.in_cs * ESZ + ch * ESZ) + WG_BIAS : 0xffffffffu;
+            cls |= (unsigned long long)((hx == 0 ? 1u : 0u) | (hx == TW + 1 ? 2u : 0u) | (hy == 0 ? 4u : 0u) | (hy == TH + 1 ? 8u : 0u)) << (4 * j);
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- fragment read bases (buffer 0): ds_read_b64_tr_b16, lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
+    const int g = lane >> 4, li = lane & 15, qr = li >> 2, pcol = li & 3;
+    const int colb = ((g & 1) * 16 + pcol * 4) * 2;
+    const int m00 = (g >> 1) * 8 + qr;
+    const char* const dy_rd0 = smem + cosub * 128 * ROWB + m00 * ROWB + colb;
+    const char* const ah_rd00 = smem + DY_BYTES + cisub * HPP * ROWB + wg_halo_pix<GEO>(m00) * ROWB + colb;
+    const char* const ah_rd10 = smem + DY_BYTES + cisub * HPP * ROWB + wg_halo_pix<GEO>(m00 + 4) * ROWB + colb;
+
+    const char* const dy_base = (const char*)p.dy + (long)p.dy_co * ESZ - WG_BIAS;
+    const char* const in_base = (const char*)p.in + (long)p.in_co * ESZ - WG_BIAS;
+
+    // requests pixel tile TILE into LDS buffer B: PW buffer-load-to-LDS instructions per wave (M0 = LDS address of the piece)
+#define WD_ISSUE(TILE, B)                                                                                         \
+    {                                                                                                             \
+        int tmi_ = (TILE);                                                                                        \
+        const int tile_x_ = tmi_ % p.tiles_x; tmi_ /= p.tiles_x;                                                  \
+        const int tile_y_ = tmi_ % p.tiles_y;                                                                     \
+        const int tile_i_ = tmi_ / p.tiles_y;                                                                     \
+        const int x0_ = tile_x_ << TWL, y0_ = tile_y_ << THL, img0_ = tile_i_ * NI;                               \
+        const unsigned tb_ = (x0_ == 0 ? 1u : 0u) | (x0_ + TW == p.W ? 2u : 0u) | (y0_ == 0 ? 4u : 0u) | (y0_ + TH == p.H ? 8u : 0u); \
+        const unsigned long long bad_ = cls & (tb_ * 0x1111111111111111ull);                                      \
+        const __amdgpu_buffer_rsrc_t rdy_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(dy_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.dy_blk) * p.dy_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rin_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+            (void*)(in_base + pix_index(img0_, y0_, x0_, p.H, p.W, p.in_blk) * p.in_cs * ESZ), 0, (int)0xfffffff0u, 0x00020000); \
+        const unsigned lb_ = lds0 + (unsigned)(B) * BUF + (unsigned)wave * 1024u;                                 \
+        _Pragma("unroll") for (int j = 0; j < PW; ++j) {                                                          \
+            const unsigned off_ = ((bad_ >> (4 * j)) & 0xfu) ? 0xffffffffu : voff[j];                             \
+            const unsigned la_ = __builtin_amdgcn_readfirstlane(lb_ + (unsigned)j * 4096u);                       \
+            if (wave + 4 * j < DY_PCS)                                                                            \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la_), "v"(off_), "s"(rdy_) : "memory"); \
+            else                                                                                                  \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la_), "v"(off_), "s"(rin_) : "memory"); \
+        }                                                                                                         \
+    }
+
+    int tile = blockIdx.x;
+    int buf = 0;
+    if (tile < p.n_tiles) WD_ISSUE(tile, 0)
+    for (; tile < p.n_tiles; tile += p.split) {
+        const int nt = tile + p.split;
+        if (nt < p.n_tiles) {
+            WD_ISSUE(nt, buf ^ 1)
+            // everything but the PW pieces just requested has landed
+            if constexpr (PW == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if constexpr (PW == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else if constexpr (PW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");                          // every wave's pieces of this buffer have landed
+        const char* const dy_rd = dy_rd0 + buf * BUF;
+        const char* const ah_rd0 = ah_rd00 + buf * BUF;
+        const char* const ah_rd1 = ah_rd10 + buf * BUF;
+        if constexpr (GEO == 0 && TAPS == 9) {
+            // a k-step is one 16-pixel tile row: each halo row is fetched once into a 3-row register window (conv_wgrad16_kernel)
+            u32x4 win[3][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) win[r][kx] = Frag16::load(ah_rd0 + (r * HW2 + kx) * ROWB, ah_rd1 + (r * HW2 + kx) * ROWB);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    win[(s + 2) % 3][kx] = Frag16::load(ah_rd0 + ((s + 2) * HW2 + kx) * ROWB, ah_rd1 + ((s + 2) * HW2 + kx) * ROWB);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) X::mma(acc[t], af, win[(s + t / 3) % 3][t % 3]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 af = Frag16::load(dy_rd + s * 16 * ROWB, dy_rd + (s * 16 + 4) * ROWB);
+                const int hs = wg_halo_pix<GEO>(s * 16) * ROWB;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = (TAPS == 9) ? t / 3 : 1, kx = (TAPS == 9) ? t % 3 : 1;
+                    const int toff = (ky * HW2 + kx) * ROWB + hs;
+                    const u32x4 bf = Frag16::load(ah_rd0 + toff, ah_rd1 + toff);
+                    X::mma(acc[t], af, bf);
+                }
+            }
+        }
+        // this buffer is requested again two tiles on: every wave must have read its fragments first
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf ^= 1;
+    }
+#undef WD_ISSUE
+
+    const int kcol = k0 + cisub * 32 + (lane & 31);
+    if (kcol < p.cin_pad) {
+        float* dst = p.dw + (p.parts > 0 ? (long)blockIdx.x * p.part_stride : 0L);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + cosub * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (n < p.cout) {
+                    float* qd = dst + ((long)n * TAPS + t) * p.cin_pad + kcol;
+                    if (p.parts > 0) *qd = acc[t][e];
+                    else atomicAdd(qd, acc[t][e]);
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // Two-group build of the lean 3x3 kernel (16x8-pixel tiles).  Phase stamps of the kernel above at one workgroup per CU (one
 // wave per SIMD): of ~6000 clocks per pixel tile only ~2580 are the 72 MFMAs; ~1830 are the commit (BatchNorm/ReLU prologue +
 // LDS writes) and ~1140 the issue of the next tile (tile coordinates by division, descriptors), and nothing overlaps them.
@@ -1015,6 +1189,20 @@ int launch_t(WgradArgs p, hipStream_t stream, int* query) {
                         attrx2_done = true;
                     }
                     hipLaunchKernelGGL((conv_wgrad16x2_kernel<T, CO_T, CI_T>), dim3(split, slabs), dim3(512), 2 * LDS, stream, p);
+                    PSSR_LAUNCH_CHECK();
+                    return PSSR_OK;
+                }
+            }
+            if constexpr (TAPS == 9 && CO_T == 64 && CI_T == 64) {
+                if (p.prologue == PSSR_PRO_NONE && pssr_tunables().wgrad_dma) {
+                    constexpr int HPP = (HP + 31) / 32 * 32;
+                    constexpr int LDS_D = 2 * ((CO_T / 32) * 128 * 64 + (CI_T / 32) * HPP * 64);
+                    static bool attrd_done = false;
+                    if (!attrd_done) {
+                        (void)hipFuncSetAttribute((const void*)conv_wgrad16d_kernel<T, CO_T, CI_T, GEO, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D);
+                        attrd_done = true;
+                    }
+                    hipLaunchKernelGGL((conv_wgrad16d_kernel<T, CO_T, CI_T, GEO, TAPS>), dim3(split, slabs), dim3(256), LDS_D, stream, p);
                     PSSR_LAUNCH_CHECK();
                     return PSSR_OK;
                 }

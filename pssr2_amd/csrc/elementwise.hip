@@ -440,6 +440,25 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply8_kernel(Ref g, Ref y, const 
     }
 }
 
+// a = relu(scale * y + shift) materialised in the storage type with the SAME helper the convolution loaders use for their BatchNorm +
+// ReLU prologue (X::bn_relu: f32 FMA, one rounding, 16-bit max) -- bit-identical to what a prologue would have staged.  The engine
+// runs it on the second stream under the forward pass so that the weight-gradient kernel can take its input by LDS-DMA.
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_relu_apply8_kernel(Ref y, const float* __restrict__ scale, const float* __restrict__ shift, MRef a, long npix,
+                                                             int cg_log2) {
+    using X = TT<T>;
+    const int cg = 1 << cg_log2;
+    const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c0 = (int)(t0 & (cg - 1)) * 8;
+    float sc[8], sh[8];
+    load4(scale + c0, sc); load4(scale + c0 + 4, sc + 4); load4(shift + c0, sh); load4(shift + c0 + 4, sh + 4);
+    const long total = npix << cg_log2;
+    for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i >> cg_log2;
+        *(u32x4*)at<T>(a, pix, c0) = X::bn_relu(*(const u32x4*)at<T>(y, pix, c0), sc, sh);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void relu_bwd_stats8_kernel(Ref dout, Ref out, Ref y, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               MRef dz, double* __restrict__ stats, long npix, int c, int cg_log2) {
@@ -718,6 +737,24 @@ int pssr_bn_bwd_apply(const void* g, int g_cs, int g_co, const void* y, int y_cs
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid1d(npix * (c / 4))), dim3(TPB), 0, (hipStream_t)s, Ref{g, g_cs, g_co},
                                          Ref{y, y_cs, y_co}, coef_a, coef_b, coef_c, MRef{dy, dy_cs, dy_co}, (long)npix, c));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_bn_relu_apply(const void* y, int y_cs, int y_co, const float* scale, const float* shift, void* a, int a_cs, int a_co, int64_t npix, int c, int dtype,
+                       pssr_stream_t s) {
+    PSSR_CHECK(y && scale && shift && a && npix > 0, PSSR_ERR_ARG, "bn_relu_apply: bad args");
+    PSSR_CHECK(dtype != PSSR_F32 && c >= 8 && c <= 8 * TPB && (c & (c - 1)) == 0 && ((y_cs | y_co | a_cs | a_co) & 7) == 0, PSSR_ERR_UNSUPPORTED,
+               "bn_relu_apply: 16-bit storage, power-of-two channel count >= 8, 16-byte aligned slices (c=%d)", c);
+    CHECK_REF("bn_relu_apply y", y_cs, y_co, c); CHECK_REF("bn_relu_apply a", a_cs, a_co, c);
+    int lg = 0;
+    while ((8 << lg) < c) ++lg;
+    const long threads = (long)npix << lg;
+    const int grid = (int)((threads + TPB - 1) / TPB < 4096 ? (threads + TPB - 1) / TPB : 4096);
+    if (dtype == PSSR_BF16)
+        hipLaunchKernelGGL(bn_relu_apply8_kernel<bf16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{y, y_cs, y_co}, scale, shift, MRef{a, a_cs, a_co}, (long)npix, lg);
+    else
+        hipLaunchKernelGGL(bn_relu_apply8_kernel<f16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{y, y_cs, y_co}, scale, shift, MRef{a, a_cs, a_co}, (long)npix, lg);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

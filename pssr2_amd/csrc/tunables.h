@@ -8,11 +8,13 @@ struct PssrTunables {
     int igemm_big;          // 256-pixel x 64-channel tiles for 3x3 layers >= 16x16 (0 off, 1 Cout <= 64, 2 all)
     int igemm_v3;           // LDS-DMA / counted-wait 3x3 loop for 16-bit layers with > 64 output channels and >= 16x16 images
     int igemm_v3_64;        // the same loop in 16x32-pixel x 64-channel tiles for layers with 33..64 output channels (0 off, 1 on)
+    int v3_lds_pad;         // experiment: KiB of unused LDS per v3 workgroup (1 workgroup per CU from ~25)
     int igemm_dbg;          // diagnostic bits of the v3 loop (0 in production)
     int igemm_ksplit;       // workgroups a split-K launch of the 128-pixel loop aims for
     int conv_epi8;          // straight-line 8-channel epilogue
     int wgrad_lean;         // lean-loader weight-gradient kernel
     int wgrad_x2;           // 3x3 weight gradients of 16x8-pixel tiles: 512-thread workgroups of two phase-shifted wave groups (0 off)
+    int wgrad_dma;          // all-DMA 3x3 weight-gradient kernel for prologue-free inputs (conv_wgrad16d_kernel)
     int wgrad_blocks;       // partial slabs of a 3x3 weight gradient
     int wgrad_blocks_1x1;   // ... of a 1x1 weight gradient
     int dwconv_tile;        // LDS-tiled depthwise 7x7

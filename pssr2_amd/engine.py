@@ -28,6 +28,11 @@ def _log2(v: int) -> int:
 
 
 _COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
+# PSSR_MATERIALISE=1 (off by default): write relu(bn(y)) out once per layer under the forward pass so that EVERY 3x3 weight gradient takes
+# the all-DMA kernel.  Measured (c2 step): the kernels get 20 % faster stand-alone (57 -> 46 us per layer) and the step 0.4 ms SLOWER
+# -- the 1.8 GB of extra HBM traffic cost more than the weight gradients' staging arithmetic, because the step is bound by memory
+# traffic, not by the second stream's kernel time
+_NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 
 class _Arena:
     """Bump allocator for the many small per-channel vectors (one memset zeroes all statistics)."""
@@ -180,6 +185,10 @@ class Engine:
         if self.reducer is not None:
             self.reducer.begin()
         self._side_begin(device)
+        if getattr(self, "_fwd_side", False):
+            # the forward pass left bn_relu_apply launches on the second stream (finished long ago): whoever reads them comes after
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._fwd_side = False
 
     def _finish_backward(self, grads):
         """Publish the gradients.  The engine owns the .grad of its parameters: a parameter without a gradient gets the
@@ -431,6 +440,7 @@ class Engine:
                 b.y, b.bn = [], []
             else:
                 b.y = [buf(*p.dims[i], hid[i]) for _ in range(nl)]
+                b.act = None
                 b.bn = [_BNState(hid[i], f32, f64) for _ in range(nl)]
             b.out = None if i < Lv - 1 else buf(*p.dims[i], hid[i])       # encoder outputs live in cat[i]
             p.enc.append(b)
@@ -444,6 +454,7 @@ class Engine:
                 b.y, b.bn = [], []
             else:
                 b.y = [buf(*p.dims[l], hid[l]) for _ in range(nl)]
+                b.act = None
                 b.bn = [_BNState(hid[l], f32, f64) for _ in range(nl)]
             b.out = buf(*p.dims[l], hid[l])
             p.dec.append(b)                                              # p.dec[l] is the block at level l
@@ -554,6 +565,32 @@ class Engine:
                 ops.bn_eval_affine(*ts, BN_EPS, st.scale, st.shift)
                 st.eval_key = key
 
+    def _materialise_ok(self, p, c):
+        """The weight gradients of this plan read materialised activations (16-bit storage, power-of-two channel counts, the all-DMA
+        kernel switched on: tunable WGRAD_DMA) instead of applying BatchNorm+ReLU in their loaders."""
+        if p.code == L.F32 or c < 8 or (c & (c - 1)) or _NO_MATERIALISE:
+            return False
+        if getattr(self, "_wgrad_dma", None) is None:
+            self._wgrad_dma = L.lib().pssr_get_option(b"WGRAD_DMA") > 0
+        return self._wgrad_dma
+
+    def _materialise(self, p, blk, k):
+        """act[k] = relu(bn_k(y[k])) on the SECOND stream, under the forward pass (which leaves that stream idle): the weight gradient of
+        conv k + 1 then takes both operands by LDS-DMA (conv_wgrad16d_kernel) -- 13 us of HBM-bound work per layer beside MFMA-bound
+        convolutions buys a weight-gradient kernel without staging registers, prologue arithmetic or LDS commit."""
+        if getattr(blk, "act", None) is None:
+            blk.act = [torch.zeros_like(blk.y[0]) for _ in range(len(blk.y) - 1)]
+        st = blk.bn[k]
+        hh, ww = p.dims[blk.level]
+        if self._side is None:
+            self._side = torch.cuda.Stream(blk.y[0].device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            ops.bn_relu_apply(blk.y[k], st.scale, st.shift, blk.act[k], p.n * hh * ww, blk.c, p.code)
+        self._fwd_side = True
+
     def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
         if getattr(blk, "a", None) is not None:          # ResBlockA (pssr2_amd/atrous.py); a first block reads the plain input
             from . import atrous as A
@@ -580,6 +617,8 @@ class Engine:
                            pro_scale=prev.scale, pro_shift=prev.shift,
                            flags=L.FLAG_STATS if train else 0, stats=blk.bn[k].stats if train else None)
             self._bn_forward(p, blk.bn[k], bn, count, train)
+            if train and k < nl - 1 and getattr(self, "_will_backward", False) and self._materialise_ok(p, blk.c):
+                self._materialise(p, blk, k)
         rp = module.respass
         if first:
             pw = self._conv(rp, fwd=dict(mode=2, center=True), dgrad=dict(mode=3, center=True)).get("fwd", p.code)
@@ -793,7 +832,10 @@ class Engine:
             conv = module.conv[3 * k]
             prev, bn_prev = blk.bn[k - 1], module.conv[3 * (k - 1) + 1]
             # conv.bias sits in front of a batch-statistics BN: its gradient is exactly zero (slot stays zeroed)
-            self._wgrad(p, grads, conv, dy, blk.c, blk.y[k - 1], blk.c, 9, pro=prev, hh=hh, ww=ww)
+            if getattr(blk, "act", None) is not None:
+                self._wgrad(p, grads, conv, dy, blk.c, blk.act[k - 1], blk.c, 9, hh=hh, ww=ww)      # materialised in the forward pass
+            else:
+                self._wgrad(p, grads, conv, dy, blk.c, blk.y[k - 1], blk.c, 9, pro=prev, hh=hh, ww=ww)
             pwd = self._conv(conv, fwd=dict(mode=0), dgrad=dict(mode=1)).get("dgrad", code)
             ops.conv2d(dy, blk.c, pwd, g, blk.c, n=n, h=hh, w=ww, epilogue=L.EPI_DGRAD_MASK, flags=L.FLAG_STATS,
                        aux=blk.y[k - 1], aux_scale=prev.scale, aux_shift=prev.shift, aux_mean=prev.mean, aux_invstd=prev.invstd,

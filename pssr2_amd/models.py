@@ -100,6 +100,7 @@ class _EngineFunction(torch.autograd.Function):
         ctx.engine = engine
         ctx.param_ids = [id(p) for p in params]
         ctx.shapes = [p.shape for p in params]
+        engine._will_backward = any(ctx.needs_input_grad[2:])      # a backward pass can follow: keep what its kernels want prepared
         return engine.forward(x, engine.model.training)
 
     @staticmethod

@@ -166,6 +166,12 @@ def bn_bwd_apply(g, y, coef_a, coef_b, coef_c, dy, npix, c, dtype, g_coff=0, y_c
                                       *_ref(dy, dy_coff), C.c_int64(npix), c, dtype, L.stream_ptr()), "pssr_bn_bwd_apply")
 
 
+def bn_relu_apply(y, scale, shift, a, npix, c, dtype, y_coff=0, a_coff=0):
+    """a = relu(scale * y + shift) in the storage type: pssr_bn_relu_apply (what a BatchNorm+ReLU prologue would stage, written out)."""
+    L.check(L.lib().pssr_bn_relu_apply(L.ptr(y), y.shape[-1], y_coff, L.ptr(scale), L.ptr(shift), L.ptr(a), a.shape[-1], a_coff, C.c_int64(npix), c, dtype,
+                                       L.stream_ptr()), "pssr_bn_relu_apply")
+
+
 def input_im2col(x, xcol, scale, shift, dtype, pre_scale=1 / 128, pre_shift=-1.0):
     n, c, h, w = x.shape
     L.check(L.lib().pssr_input_im2col(L.ptr(x), L.ptr(xcol), n, c, h, w, xcol.shape[-1], C.c_float(pre_scale), C.c_float(pre_shift),

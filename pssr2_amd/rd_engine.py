@@ -163,6 +163,7 @@ class RDEngine(Engine):
                 b.y, b.bn = [], []
             else:
                 b.y = [buf(*p.dims[k], hid[k]) for _ in range(nl)]
+                b.act = None
                 b.bn = [_BNState(hid[k], f32, f64) for _ in range(nl)]
             b.out = buf(*p.dims[k], hid[k])
             p.dec.append(b)

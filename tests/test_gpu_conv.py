@@ -253,3 +253,66 @@ def test_conv2d_dual_source_split_k(dt):
                    flags=L.FLAG_RELU)
         tol = 2e-2 if dt == torch.bfloat16 else 1e-4
         torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=tol, atol=tol * float(ref.abs().max()))
+
+
+WGD_CASES = [
+    # n, cin, cout, h, w: 3x3, 64x64 slabs (what conv_wgrad16d_kernel serves)
+    (4, 64, 64, 32, 32),       # full channel tiles, 8x16 pixel tiles, several tiles per workgroup
+    (2, 96, 128, 16, 48),      # channel tail on the input side (96 = 64 + 32), two cout tiles
+    (40, 64, 64, 16, 16),      # many pixel tiles per workgroup: both LDS buffers in rotation, odd tile counts
+    (8, 64, 64, 8, 8),         # 8x8 maps: tiles of two images (GEO 1), every halo pixel on an image border
+    (3, 128, 80, 16, 16),      # cout tail (80 = 64 + 16)
+    (1, 64, 64, 8, 16),        # a single pixel tile: no prefetch at all
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", WGD_CASES)
+def test_conv_wgrad_all_dma_kernel(case, dt):
+    """Prologue-free 3x3 weight gradient through the all-DMA kernel (both operands global -> LDS by buffer_load ... lds, double-buffered;
+    tunable WGRAD_DMA): against torch's conv2d_weight on the same 16-bit operands, and bit for bit against the register-staged kernel
+    (same tiles in the same order, same MFMA sequence: identical partial slabs)."""
+    from pssr2_amd import ops, _lib as L
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    code = ops.dtype_code(dt)
+    a = torch.randn(n, cin, h, w, generator=g).to(dt).float()
+    dy = torch.randn(n, cout, h, w, generator=g).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(a, (cout, cin, 3, 3), dy, padding=1)
+    cpad, copad = ops.pad_to(cin, 16), ops.pad_to(cout, 16)
+
+    def run(dma):
+        old = L.lib().pssr_set_option(b"WGRAD_DMA", dma)
+        try:
+            parts = ops.conv2d_wgrad_parts(_nhwc(dy, copad, dt), cout, _nhwc(a, cpad, dt), cpad, 9, n=n, h=h, w=w, dtype=code)
+            dw = torch.full((cout, cin, 3, 3), 9.0, device="cuda")
+            ops.unpack_conv_wgrad(parts, dw, k_pad=cpad)
+            torch.cuda.synchronize()
+            return parts.clone(), dw
+        finally:
+            L.lib().pssr_set_option(b"WGRAD_DMA", old)
+    p1, dw1 = run(1)
+    p0, dw0 = run(0)
+    np.testing.assert_allclose(dw1.cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+    assert torch.equal(p1, p0) and torch.equal(dw1, dw0)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_bn_relu_apply_equals_the_loader_prologue(dt):
+    """pssr_bn_relu_apply writes relu(scale * y + shift) exactly as the convolution loaders' BatchNorm+ReLU prologue stages it: the
+    weight gradient with the prologue on the raw tensor == the prologue-free weight gradient on the materialised tensor, bit for bit."""
+    from pssr2_amd import ops
+    n, c, cout, h, w = 4, 64, 64, 16, 32
+    g = torch.Generator().manual_seed(5)
+    code = ops.dtype_code(dt)
+    y = _nhwc(torch.randn(n, c, h, w, generator=g) * 3, c, dt)
+    dy = _nhwc(torch.randn(n, cout, h, w, generator=g), cout, dt)
+    scale, shift = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    act = torch.zeros_like(y)
+    ops.bn_relu_apply(y, scale, shift, act, n * h * w, c, code)
+    want = torch.relu(y.float() * scale + shift)           # (torch rounds the product; the kernel's FMA does not: compare within an ulp)
+    torch.testing.assert_close(act.float(), want, rtol=2e-3 if dt == torch.float16 else 1e-2, atol=1e-3)
+    assert torch.equal(act > 0, want.to(dt) > 0) or float(((act > 0) != (want.to(dt) > 0)).float().mean()) < 1e-4
+    with_pro = ops.conv2d_wgrad_parts(dy, cout, y, c, 9, n=n, h=h, w=w, dtype=code, pro_scale=scale, pro_shift=shift)
+    without = ops.conv2d_wgrad_parts(dy, cout, act, c, 9, n=n, h=h, w=w, dtype=code)
+    assert torch.equal(with_pro, without)
