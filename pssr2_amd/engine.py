@@ -32,6 +32,7 @@ _COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
 # the all-DMA kernel.  Measured (c2 step): the kernels get 20 % faster stand-alone (57 -> 46 us per layer) and the step 0.4 ms SLOWER
 # -- the 1.8 GB of extra HBM traffic cost more than the weight gradients' staging arithmetic, because the step is bound by memory
 # traffic, not by the second stream's kernel time
+_ABLATE_XCOL = __import__("os").environ.get("PSSR_ABLATE_XCOL", "0") == "1"      # timing ablation (wrong gradients): skip the two passes over d(pre) that serve the input channel
 _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 
 class _Arena:
@@ -764,12 +765,16 @@ class Engine:
         gb_pre[self.pre_perm_long] = gpb
         grads[id(rec.pre.bias)] = gb_pre
         self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
-        self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
-                    n_perm=self.pre_perm, hh=h, ww=w)
+        if not _ABLATE_XCOL:
+            self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
+                        n_perm=self.pre_perm, hh=h, ww=w)
         self._ready(grads, list(rec.parameters()))
         cpre = self._convs[id(rec.pre)]
         ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
-        ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
+        if not _ABLATE_XCOL:
+            # (also tried on the second stream, off the dependent chain -- it only feeds the input BatchNorm's parameter gradients at the
+            # very end: 12.02 / 12.07 vs 12.00 / 11.95 ms per step, no gain; leaving both passes over d(pre) out entirely is worth 0.16-0.3 ms)
+            ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,

@@ -12,7 +12,7 @@ for sub in "ab":
     f = glob.glob(f"gpurun_out/pmc_conv/{sub}/**/*counter_collection.csv", recursive=True)[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        m = re.search(r"\d\d(conv_(?:v3|igemm|flat|wgrad16|wgrad16_1x1)_kernel)I(.*?)EEvN", k)
+        m = re.search(r"\d\d(conv_(?:v3|igemm|flat|wgrad16d|wgrad16|wgrad16_1x1)_kernel)I(.*?)EEvN", k)
         if not m: continue
         key = m.group(1) + " " + m.group(2).replace("DF16b", "bf16 ").replace("Li", "").replace("E", " ").strip() + " | grid " + r["Grid_Size"]
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[(key, r["Counter_Name"])] += 1
