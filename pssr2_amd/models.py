@@ -92,6 +92,28 @@ def get_resblock(in_channels: int, out_channels: int, dilations, depth: int):
     return ResBlock(in_channels, out_channels, depth)
 
 
+def _seg_pairs(segs, ndim):
+    """Cartesian product of the per-dimension (source start, length, destination start) segments as pairs of index tuples."""
+    import itertools
+    per_dim = [s if s is not None else [None] for s in segs] + [[None]] * (ndim - len(segs))
+    for combo in itertools.product(*per_dim):
+        src = tuple(slice(None) if c is None else slice(c[0], c[0] + c[1]) for c in combo)
+        dst = tuple(slice(None) if c is None else slice(c[2], c[2] + c[1]) for c in combo)
+        yield src, dst
+
+
+def _scatter(padded, real, segs):
+    with torch.no_grad():
+        for src, dst in _seg_pairs(segs, real.dim()):
+            padded[dst] = real[src]
+
+
+def _gather(real, padded, segs):
+    with torch.no_grad():
+        for src, dst in _seg_pairs(segs, real.dim()):
+            real[src] = padded[dst]
+
+
 class _EngineFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are engine kernel sequences."""
 
@@ -155,10 +177,99 @@ class ResUNet(nn.Module):
         self.reconstruction = Reconstruction(channels[0], channels[1], hidden[0], scale)
 
         self.channels, self.hidden, self.depth = channels, hidden, depth
+        self.hidden_real = list(hidden)
+        if any(h % 16 for h in hidden):
+            # widths the kernels do not take (K chunks of 16 channels, 16-byte channel slices): run the net with every hidden width rounded
+            # up to a multiple of 16 and the extra channels held at exactly zero; checkpoints keep the reference's shapes (_embed_padded)
+            if dilations or pool_sizes:
+                raise ValueError("the MI355X path takes hidden widths that are not multiples of 16 only for the plain ResUNet "
+                                 f"(no dilations / pool_sizes); got hidden={hidden}")
+            if any(h % 4 for h in hidden[1:]):
+                raise ValueError(f"hidden[1:] must be divisible by 4 (pixel_shuffle(2) of every deeper level); got hidden={hidden}")
+            self._embed_padded()
         self.compute_dtype = torch.float32
         self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
         self.autograd_grads = False   # True: return parameter gradients to autograd (torch.autograd.grad, gradient hooks) instead of publishing .grad
         self._engine = Engine(self)
+
+    # ---- hidden widths that are not multiples of 16 (pssr/models/resunet.py:8-17 accepts any)
+    def _embed_padded(self):
+        """Replace every parameter / BatchNorm buffer by a zero-padded copy with all hidden widths rounded up to multiples of 16.
+
+        The padded channels stay exactly zero through training: a padded output channel has zero weights, zero bias, zero BatchNorm
+        affine (its activation is 0 after every layer), every consumer's weights for it are zero (so its gradient is 0), and a zero weight
+        with a zero gradient does not move under AdamW or SGD.  ``state_dict()`` / ``load_state_dict()`` slice and pad, so checkpoints
+        carry the reference's keys and shapes; ``parameters()`` are the padded tensors (``hidden_real`` keeps the widths asked for)."""
+        real = self.hidden_real
+        pad = [(h + 15) // 16 * 16 for h in real]
+        cin, cout = self.channels
+        r2 = self.reconstruction.scale ** 2
+        Lv = len(real)
+        self._embed = {}                       # parameter / buffer name -> (real shape, [per dim: [(src start, length, dst start)]], fill)
+
+        def put(mod, prefix, name, shape_pad, segs, fill=0.0):
+            t = getattr(mod, name)
+            new = torch.full(shape_pad, fill, dtype=t.dtype)
+            src = t.detach()
+            self._embed[f"{prefix}.{name}"] = (tuple(src.shape), segs, fill)
+            _scatter(new, src, segs)
+            if name in mod._parameters:
+                mod._parameters[name] = nn.Parameter(new)
+            else:
+                mod._buffers[name] = new
+
+        def conv(mod, prefix, out_segs, out_pad, in_segs, in_pad):
+            k = mod.weight.shape[-1]
+            put(mod, prefix, "weight", (out_pad, in_pad, k, k), [out_segs, in_segs, None, None])
+            put(mod, prefix, "bias", (out_pad,), [out_segs])
+
+        def bn(mod, prefix, c, cp):
+            seg = [(0, c, 0)]
+            put(mod, prefix, "weight", (cp,), [seg])          # gamma of a padded channel: 0 (it normalises an all-zero channel)
+            put(mod, prefix, "bias", (cp,), [seg])
+            put(mod, prefix, "running_mean", (cp,), [seg])
+            put(mod, prefix, "running_var", (cp,), [seg], fill=1.0)
+
+        def block(mod, prefix, in_segs, in_pad, c, cp):
+            nl = max(self.depth, 0) + 1
+            for k in range(nl):
+                conv(mod.conv[3 * k], f"{prefix}.conv.{3 * k}", [(0, c, 0)], cp, in_segs if k == 0 else [(0, c, 0)], in_pad if k == 0 else cp)
+                bn(mod.conv[3 * k + 1], f"{prefix}.conv.{3 * k + 1}", c, cp)
+            conv(mod.respass, f"{prefix}.respass", [(0, c, 0)], cp, in_segs, in_pad)
+
+        for i in range(Lv):
+            ci, cip = (cin, cin) if i == 0 else (real[i - 1], pad[i - 1])
+            block(self.encoder[i], f"encoder.{i}", [(0, ci, 0)], cip, real[i], pad[i])
+        for j in range(Lv - 1):                # decoder j works at level l = Lv - 2 - j on cat([shuffle(level l + 1) | encoder l])
+            l = Lv - 2 - j
+            up, upp = real[l + 1] // 4, pad[l + 1] // 4
+            block(self.decoder[j], f"decoder.{j}", [(0, up, 0), (up, real[l], upp)], upp + pad[l], real[l], pad[l])
+        h0, h0p = real[0], pad[0]
+        conv(self.reconstruction.pre, "reconstruction.pre", [(0, r2 * h0, 0)], r2 * h0p, [(0, h0, 0), (h0, cin, h0p)], h0p + cin)
+        conv(self.reconstruction.conv, "reconstruction.conv", [(0, cout, 0)], cout, [(0, h0, 0)], h0p)
+        self.hidden = pad
+        self._register_state_dict_hook(ResUNet._slice_state)
+        self._register_load_state_dict_pre_hook(self._pad_incoming)
+
+    @staticmethod
+    def _slice_state(module, state_dict, prefix, local_metadata):
+        for name, (shape, segs, _) in module._embed.items():
+            key = prefix + name
+            if key in state_dict:
+                out = torch.empty(shape, dtype=state_dict[key].dtype, device=state_dict[key].device)
+                _gather(out, state_dict[key], segs)
+                state_dict[key] = out
+
+    def _pad_incoming(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        for name, (shape, segs, fill) in self._embed.items():
+            key = prefix + name
+            t = state_dict.get(key)
+            if t is not None and tuple(t.shape) == shape:
+                new = torch.full(own[name].shape, fill, dtype=t.dtype, device=t.device)
+                _scatter(new, t, segs)
+                state_dict[key] = new
 
     def forward(self, x):
         params = [p for p in self.parameters()]

@@ -335,3 +335,64 @@ def test_autograd_grad_and_hooks_when_asked(golden):
     hook.remove()
     assert len(seen) == 1 and seen[0] == float(want[list(dict(model2.named_parameters()))[3]].abs().sum())
     assert torch.equal(params[0].grad, want[list(dict(model2.named_parameters()))[0]])
+
+
+@pytest.mark.parametrize("hidden", [[12, 24, 48], [24, 48, 96], [8, 16]])
+def test_hidden_widths_that_are_not_multiples_of_16(hidden):
+    """pssr/models/resunet.py:8-17 takes any hidden widths (doubling ones run); the kernels take multiples of 16.  ResUNet embeds such a
+    net in zero-padded parameters (models.ResUNet._embed_padded): outputs and the real-shaped gradients equal the CPU oracle's on the
+    reference-shaped state_dict, checkpoints keep the reference's shapes, and the padding stays exactly zero through an optimizer step."""
+    from oracle import model_ref as M
+    from pssr2_amd.models import ResUNet
+    torch.manual_seed(3)
+    model = ResUNet(channels=[2, 1], hidden=hidden, depth=1, scale=2).cuda()
+    assert model.hidden_real == hidden and all(h % 16 == 0 for h in model.hidden)
+    with torch.no_grad():                                  # non-trivial BatchNorm state (through the reference-shaped state_dict)
+        sd = model.state_dict()
+        g = torch.Generator().manual_seed(1)
+        for k, v in sd.items():
+            if k.endswith("running_mean"):
+                sd[k] = torch.rand(v.shape, generator=g) * 0.2 - 0.1
+            elif k.endswith("running_var") or (k.endswith("weight") and v.dim() == 1):
+                sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        model.load_state_dict(sd)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert sd["encoder.0.conv.0.weight"].shape == (hidden[0], 2, 3, 3) and sd["reconstruction.pre.weight"].shape == (4 * hidden[0], hidden[0] + 2, 3, 3)
+    x = torch.rand(3, 2, 16, 16, generator=torch.Generator().manual_seed(2)) * 255
+    target = torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(4)) * 255
+    model.eval()
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+        y_ref, _ = M.resunet_forward(x, sd, len(hidden), 1, 2, train=False)
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=2e-4, atol=2e-3)
+    model.train()
+    p64 = {k: (v.double().requires_grad_(True) if "running" not in k else v.double()) if v.dtype.is_floating_point else v for k, v in sd.items()}
+    y64, _ = M.resunet_forward(x.double(), p64, len(hidden), 1, 2, train=True)
+    torch.nn.functional.mse_loss(y64 / 255, target.double() / 255).backward()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1)
+    yt = model(x.cuda())
+    np.testing.assert_allclose(yt.detach().cpu().numpy(), y64.detach().numpy(), rtol=2e-4, atol=3e-3)
+    torch.nn.functional.mse_loss(yt / 255, target.cuda() / 255).backward()
+    from pssr2_amd.models import _gather
+    worst = 0.0
+    for name, prm in model.named_parameters():
+        shape, segs, _ = model._embed.get(name, (tuple(prm.shape), [], 0.0))          # (norm.* is not padded)
+        got = torch.empty(shape, dtype=torch.float32)
+        _gather(got, prm.grad.detach().cpu(), segs)
+        truth = p64[name].grad
+        scale = float(truth.abs().max())
+        if scale < 1e-9:
+            assert float(got.abs().max()) <= 1e-6, name
+            continue
+        worst = max(worst, float((got.double() - truth).abs().max()) / scale)
+        # the padding carries no gradient: everything outside the real block is exactly zero
+        assert float(prm.grad.abs().sum()) == pytest.approx(float(got.abs().sum()), rel=1e-6), name
+    assert worst < 5e-3, worst            # tiny untrained nets: a ReLU decision within round-off moves upstream gradients (see above)
+    opt.step()
+    sd_after = model.state_dict()
+    for name, prm in model.named_parameters():
+        shape, segs, _ = model._embed.get(name, (tuple(prm.shape), [], 0.0))
+        real = torch.empty(shape)
+        _gather(real, prm.detach().cpu(), segs)
+        assert float(prm.detach().abs().sum()) == pytest.approx(float(real.abs().sum()), rel=1e-6), name      # the padding is still zero
+        assert torch.equal(sd_after[name].cpu(), real)
