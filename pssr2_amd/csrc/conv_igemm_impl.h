@@ -402,7 +402,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int h = lane >> 5, r = lane & 31;
 
-    const int bid = blockIdx.x;
+    // workgroups go round-robin to the 8 XCDs: renumber them so that consecutive tiles -- the channel tiles of one pixel tile first, then
+    // its neighbour along x -- run on ONE XCD, whose L2 then serves the shared input tile (with bid % tiles_n on different XCDs every
+    // L2 fetched it again: up to 8 x for the 1024-channel layers) and the shared halo columns (round 3; the 1x1 kernel below had it)
+    int bid = blockIdx.x;
+    if (p.ksplit <= 1 && !(p.dbg & 64)) {
+        const int per = gridDim.x >> 3;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+    }
     const int tn = bid % p.tiles_n;
     int tmi = bid / p.tiles_n;
     const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;

@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
 #endif
 
-    const int bid = blockIdx.x;
+    // consecutive tiles (channel tiles of a pixel tile first, then its neighbour along x) on ONE XCD: conv_igemm_kernel
+    int bid = blockIdx.x;
+    if (p.ksplit <= 1 && !(p.dbg & 64)) {
+        const int per = gridDim.x >> 3;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+    }
     const int tn = bid % p.tiles_n;
     int tmi = bid / p.tiles_n;
     const int tile_x = tmi % p.tiles_x; tmi /= p.tiles_x;
