@@ -517,7 +517,7 @@ def main():
         comm_ms = 1e3 * min(ts[1:])
         ranks = [None] * world
         torch.distributed.all_gather_object(ranks, (rank, local, os.uname().nodename))
-        stp = fastpath.LAST_TRAIN_STEPPER
+        stp = getattr(model._engine, "last_train_stepper", None)
         exposed = stp.exposed_comm_ms(last=args.steps) if stp is not None else None
         if rank == 0:
             res["comm"] = {"allreduce_bytes_per_step": int(flat.numel() * 4), "comm_ms": round(comm_ms, 3),

@@ -298,7 +298,10 @@ int pssr_bilinear_down_u8(const uint8_t* hr, uint8_t* tmp, uint8_t* lr, int plan
     PSSR_CHECK(hr && tmp && lr && planes > 0 && H > 0 && W > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "bilinear_down_u8: bad args");
     PSSR_CHECK(H >= h && W >= w && (double)W / w <= 19.0 && (double)H / h <= 19.0, PSSR_ERR_UNSUPPORTED, "bilinear_down_u8: reduction ratio must be in [1, 19]");
     long rows = (long)planes * H;
-    hipLaunchKernelGGL(resample_h_kernel, dim3(cdiv(w, 64), (unsigned)(rows < 65535 ? rows : 65535)), dim3(64), 0, (hipStream_t)s, hr, tmp, planes, H, W, w);
+    // a thread computes its output column's taps once (float arithmetic) and walks ~16 rows with them: with one row per thread the launch
+    // spent its time on the taps (66 -> 20 us for a c2 batch)
+    const long row_groups = (rows + 15) / 16;
+    hipLaunchKernelGGL(resample_h_kernel, dim3(cdiv(w, 64), (unsigned)(row_groups < 65535 ? row_groups : 65535)), dim3(64), 0, (hipStream_t)s, hr, tmp, planes, H, W, w);
     PSSR_LAUNCH_CHECK();
     hipLaunchKernelGGL(resample_v_kernel, dim3(cdiv(w, 128), h, planes < 1024 ? planes : 1024), dim3(128), 0, (hipStream_t)s, tmp, lr, planes, H, h, w);
     PSSR_LAUNCH_CHECK();

@@ -27,7 +27,6 @@ from .util import SSIMLoss as _SSIMLoss
 # stream capture in thread-local mode: a DataLoader's pin-memory thread allocates pinned host memory while the main thread captures
 # (in the default global mode any such call from ANY thread invalidates the capture)
 _CAPTURE_MODE = "thread_local"
-LAST_TRAIN_STEPPER = None      # the stepper of the most recent train_paired call (bench.py reads its communication statistics)
 
 
 def enabled():
@@ -178,8 +177,7 @@ class TrainStepper:
         self.split = self.world > 1 and os.environ.get("PSSR_OVERLAP", "1") != "0"
         self.graph2, self.split_at = None, 0
         self.comm_events = [] if os.environ.get("PSSR_COMM_STATS") == "1" else None     # (after graph 2, after the all-reduces) per step
-        global LAST_TRAIN_STEPPER
-        LAST_TRAIN_STEPPER = self
+        self.engine.last_train_stepper = self       # the stepper of the model's most recent train_paired call (bench.py / tests read its statistics)
 
     def begin_epoch(self, order):
         self.n = self.cur.load(order)

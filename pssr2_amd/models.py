@@ -139,13 +139,15 @@ class _EngineFunction(torch.autograd.Function):
 
 class ResUNet(nn.Module):
     def __init__(self, channels=1, hidden=[64, 128, 256, 512, 1024], scale: int = 4, depth: int = 3,
-                 dilations=None, pool_sizes=None, encoder_pool: bool = False):
+                 dilations=None, pool_sizes=None, encoder_pool: bool = False, *, storage_multiple: int = 8):
         r"""Residual U-Net with a ``scale``-times upscaling head; same arguments as the reference
         (pssr/models/resunet.py:8-17), including ``dilations`` (atrous blocks, no input BatchNorm) and ``pool_sizes`` /
         ``encoder_pool`` (PSP pooling): SURVEY.md §8f-4.
 
         Extra attribute: ``compute_dtype``: torch.float32 (exact-f32 MFMA, default), torch.bfloat16 or torch.float16
-        (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16); ``infer_dtype``: storage type of
+        (16-bit storage / f32 accumulate; ``train_paired`` adds dynamic loss scaling for float16); keyword-only ``storage_multiple``
+        (8: what float32 compute needs; pass 16 to run hidden widths such as 24 or 40 with 16-bit storage): hidden widths that are not
+        multiples of it run zero-padded (``_embed_padded``), checkpoints keep the reference's shapes; ``infer_dtype``: storage type of
         eval-mode forwards (default None: float16 for a bfloat16 model -- 3 more mantissa bits at the same rate keep inference within
         1e-3 dB of the f32 path -- else ``compute_dtype``).
         """
@@ -178,22 +180,24 @@ class ResUNet(nn.Module):
 
         self.channels, self.hidden, self.depth = channels, hidden, depth
         self.hidden_real = list(hidden)
-        if any(h % 16 for h in hidden):
-            # widths the kernels do not take (K chunks of 16 channels, 16-byte channel slices): run the net with every hidden width rounded
-            # up to a multiple of 16 and the extra channels held at exactly zero; checkpoints keep the reference's shapes (_embed_padded)
+        if storage_multiple not in (8, 16):
+            raise ValueError(f"storage_multiple must be 8 or 16, got {storage_multiple}")
+        if any(h % storage_multiple for h in hidden) or any(h % 16 for h in hidden[1:]):
+            # widths the kernels do not take (K chunks of 8 / 16 channels, 16-byte channel slices): run the net with every hidden width
+            # rounded up and the extra channels held at exactly zero; checkpoints keep the reference's shapes (_embed_padded)
             if dilations or pool_sizes:
-                raise ValueError("the MI355X path takes hidden widths that are not multiples of 16 only for the plain ResUNet "
+                raise ValueError(f"the MI355X path takes hidden widths that are not multiples of {storage_multiple} only for the plain ResUNet "
                                  f"(no dilations / pool_sizes); got hidden={hidden}")
             if any(h % 4 for h in hidden[1:]):
                 raise ValueError(f"hidden[1:] must be divisible by 4 (pixel_shuffle(2) of every deeper level); got hidden={hidden}")
-            self._embed_padded()
+            self._embed_padded(storage_multiple)
         self.compute_dtype = torch.float32
         self.infer_dtype = None       # storage type of eval-mode forwards; None: float16 for a bfloat16 model, else compute_dtype (Engine.storage_dtype)
         self.autograd_grads = False   # True: return parameter gradients to autograd (torch.autograd.grad, gradient hooks) instead of publishing .grad
         self._engine = Engine(self)
 
     # ---- hidden widths that are not multiples of 16 (pssr/models/resunet.py:8-17 accepts any)
-    def _embed_padded(self):
+    def _embed_padded(self, mult=16):
         """Replace every parameter / BatchNorm buffer by a zero-padded copy with all hidden widths rounded up to multiples of 16.
 
         The padded channels stay exactly zero through training: a padded output channel has zero weights, zero bias, zero BatchNorm
@@ -201,7 +205,7 @@ class ResUNet(nn.Module):
         with a zero gradient does not move under AdamW or SGD.  ``state_dict()`` / ``load_state_dict()`` slice and pad, so checkpoints
         carry the reference's keys and shapes; ``parameters()`` are the padded tensors (``hidden_real`` keeps the widths asked for)."""
         real = self.hidden_real
-        pad = [(h + 15) // 16 * 16 for h in real]
+        pad = [(h + m - 1) // m * m for h, m in zip(real, [mult] + [16] * (len(real) - 1))]      # deeper levels: 16 (pixel-shuffle slices)
         cin, cout = self.channels
         r2 = self.reconstruction.scale ** 2
         Lv = len(real)

@@ -112,7 +112,7 @@ def fastpath(rank, world):
                            seed=21 + rank)
     opt = FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3)
     tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 2, device="cuda", log_frequency=2)
-    stp = FP.LAST_TRAIN_STEPPER
+    stp = getattr(model._engine, "last_train_stepper", None)
     assert stp is not None and stp.world == 2 and stp.graph is not None
     assert stp.graph2 is not None, "the two-graph split was not captured"
     assert len(tl) > 0 and len(vl) == 2 and all(np.isfinite(tl)) and all(np.isfinite(vl))
@@ -143,10 +143,9 @@ def syncbn_fast(rank, world):
     ds = DeviceTileDataset(_tiles(40, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.1, rotation=True, device="cuda",
                            seed=4 + rank)
     assert not FP.supports(model, ds, "cuda")
-    FP.LAST_TRAIN_STEPPER = None
     opt = FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3)
     tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 1, device="cuda", log_frequency=1)
-    assert FP.LAST_TRAIN_STEPPER is None and len(tl) > 0 and all(np.isfinite(tl)) and all(np.isfinite(vl))
+    assert getattr(model._engine, "last_train_stepper", None) is None and len(tl) > 0 and all(np.isfinite(tl)) and all(np.isfinite(vl))
     cs = torch.tensor([float(sum(p.detach().double().abs().sum() for p in model.parameters()))], dtype=torch.float64).cuda()
     both = [torch.zeros_like(cs) for _ in range(world)]
     dist.all_gather(both, cs)

@@ -216,10 +216,9 @@ def _run_train_host(host_graph, fused, pin):
 
         def cb(loc):
             seen.append((loc["batch_idx"], tuple(loc["hr_hat"].shape), float(loc["loss"].detach()), float(loc["hr"].sum()), float(loc["lr"].sum())))
-        FP.LAST_TRAIN_STEPPER = None
         tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), opt, 2, device="cuda", log_frequency=2, callbacks=[cb],
                               dataloader_kwargs=dict(pin_memory=True) if pin else None)
-        stp = FP.LAST_TRAIN_STEPPER
+        stp = getattr(model._engine, "last_train_stepper", None)
         assert (stp is not None and stp.host and stp.graph is not None) == host_graph
         return tl, vl, {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, seen
     finally:

@@ -345,8 +345,9 @@ def test_hidden_widths_that_are_not_multiples_of_16(hidden):
     from oracle import model_ref as M
     from pssr2_amd.models import ResUNet
     torch.manual_seed(3)
-    model = ResUNet(channels=[2, 1], hidden=hidden, depth=1, scale=2).cuda()
+    model = ResUNet(channels=[2, 1], hidden=hidden, depth=1, scale=2, storage_multiple=16).cuda()
     assert model.hidden_real == hidden and all(h % 16 == 0 for h in model.hidden)
+    assert ResUNet(hidden=[8, 16, 32]).hidden == [8, 16, 32]           # multiples of 8 run as they are with float32 compute
     with torch.no_grad():                                  # non-trivial BatchNorm state (through the reference-shaped state_dict)
         sd = model.state_dict()
         g = torch.Generator().manual_seed(1)
