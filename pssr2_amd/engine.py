@@ -29,10 +29,11 @@ def _log2(v: int) -> int:
 
 _COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
 # PSSR_MATERIALISE=1 (off by default): write relu(bn(y)) out once per layer under the forward pass so that EVERY 3x3 weight gradient takes
-# the all-DMA kernel.  Measured (c2 step): the kernels get 20 % faster stand-alone (57 -> 46 us per layer) and the step 0.4 ms SLOWER
-# -- the 1.8 GB of extra HBM traffic cost more than the weight gradients' staging arithmetic, because the step is bound by memory
-# traffic, not by the second stream's kernel time
+# the all-DMA kernel.  Measured (c2 step): the kernels get 20 % faster stand-alone (57 -> 46 us per layer) and the step does not move
+# (11.51 / 11.49 vs 11.37 / 11.53 ms): the backward phase is two balanced queues, and the forward convolutions slow down by what the
+# 27 extra launches cost
 _ABLATE_XCOL = __import__("os").environ.get("PSSR_ABLATE_XCOL", "0") == "1"      # timing ablation (wrong gradients): skip the two passes over d(pre) that serve the input channel
+_XCOL_SIDE = __import__("os").environ.get("PSSR_XCOL_SIDE", "0") == "1"
 _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 
 class _Arena:
@@ -186,6 +187,7 @@ class Engine:
         if self.reducer is not None:
             self.reducer.begin()
         self._side_begin(device)
+        self._flush_fwd()
         if getattr(self, "_fwd_side", False):
             # the forward pass left bn_relu_apply launches on the second stream (finished long ago): whoever reads them comes after
             torch.cuda.current_stream().wait_stream(self._side)
@@ -585,11 +587,24 @@ class Engine:
         hh, ww = p.dims[blk.level]
         if self._side is None:
             self._side = torch.cuda.Stream(blk.y[0].device)
+        # the dependency is taken now, the launch waits until the launch stream has issued its own next kernel (_flush_fwd): in a captured
+        # graph the FIRST-created successor of a node stays on the node's hardware queue, and it has to be the next convolution, not this
+        # side kernel (Engine._on_side: the same rule for the weight gradients)
+        self._flush_fwd()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        n_el, c, code = p.n * hh * ww, blk.c, p.code
+        self._fwd_deferred = (ev, lambda: ops.bn_relu_apply(blk.y[k], st.scale, st.shift, blk.act[k], n_el, c, code))
+
+    def _flush_fwd(self):
+        d = getattr(self, "_fwd_deferred", None)
+        if d is None:
+            return
+        self._fwd_deferred = None
+        ev, fn = d
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
-            ops.bn_relu_apply(blk.y[k], st.scale, st.shift, blk.act[k], p.n * hh * ww, blk.c, p.code)
+            fn()
         self._fwd_side = True
 
     def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
@@ -617,6 +632,7 @@ class Engine:
                 ops.conv2d(blk.y[k - 1], blk.c, pw, blk.y[k], blk.c, n=n, h=hh, w=ww, bias=conv.bias,
                            pro_scale=prev.scale, pro_shift=prev.shift,
                            flags=L.FLAG_STATS if train else 0, stats=blk.bn[k].stats if train else None)
+                self._flush_fwd()
             self._bn_forward(p, blk.bn[k], bn, count, train)
             if train and k < nl - 1 and getattr(self, "_will_backward", False) and self._materialise_ok(p, blk.c):
                 self._materialise(p, blk, k)
@@ -683,6 +699,7 @@ class Engine:
             A.psp_forward(self, p.rpool, m.reconstruction_pool, feat, 0, n, code, p.rpool_out, 0, train)
             feat = p.rpool_out
         out = self._head_forward(p, feat, x)
+        self._flush_fwd()
         self.saved = (p, x) if train else None
         return out
 
@@ -772,9 +789,17 @@ class Engine:
         cpre = self._convs[id(rec.pre)]
         ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
         if not _ABLATE_XCOL:
-            # (also tried on the second stream, off the dependent chain -- it only feeds the input BatchNorm's parameter gradients at the
-            # very end: 12.02 / 12.07 vs 12.00 / 11.95 ms per step, no gain; leaving both passes over d(pre) out entirely is worth 0.16-0.3 ms)
-            ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad1", code), bw.dxcol_b, self.xc, n=n, h=h, w=w)
+            # the 16-channel data gradient of the input source only feeds the input BatchNorm's parameter gradients at the very end of the
+            # pass: on the second stream it is off the dependent chain (the two queues of the backward phase end within 0.1 ms of each
+            # other, so this pays only together with something that lightens the weight-gradient queue: PSSR_XCOL_SIDE)
+            pw1 = cpre.get("dgrad1", code)
+
+            def dgrad_x():
+                ops.conv2d(bw.dpre, cpre_n, pw1, bw.dxcol_b, self.xc, n=n, h=h, w=w)
+            if self._side_on and _XCOL_SIDE:
+                self._on_side([bw.dpre, bw.dxcol_b], dgrad_x)
+            else:
+                dgrad_x()
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,
@@ -926,6 +951,7 @@ class Engine:
         # ---- input BatchNorm parameters
         st = p.bn_in
         st.bstats.zero_()
+        self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream)
         ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         self.bn_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)

@@ -420,6 +420,7 @@ class RDEngine(Engine):
             A.psp_forward(self, p.rpool, m.reconstruction_pool, p.feat, 0, n, code, p.rpool_out, 0, train)
             feat = p.rpool_out
         out = self._head_forward(p, feat, x)
+        self._flush_fwd()
         self.saved = (p, x) if train else None
         return out
 
@@ -570,6 +571,7 @@ class RDEngine(Engine):
         # ---- input BatchNorm parameters (gradient sources: head im2col + stem patches)
         stn = p.bn_in
         stn.bstats.zero_()
+        self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream: Engine._head_backward)
         ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         self.bn_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)

@@ -397,3 +397,34 @@ def test_hidden_widths_that_are_not_multiples_of_16(hidden):
         _gather(real, prm.detach().cpu(), segs)
         assert float(prm.detach().abs().sum()) == pytest.approx(float(real.abs().sum()), rel=1e-6), name      # the padding is still zero
         assert torch.equal(sd_after[name].cpu(), real)
+
+
+def test_materialised_activations_and_side_stream_xcol_give_the_same_gradients(golden, monkeypatch):
+    """The two opt-in schedules of DESIGN.md section 4 (PSSR_MATERIALISE=1: relu(bn(y)) written out under the forward pass so that every
+    3x3 weight gradient takes the all-DMA kernel; PSSR_XCOL_SIDE=1: the input channel's data gradient on the second stream) change
+    where and when kernels run, not what they compute: every parameter gradient is bit-identical to the default schedule's."""
+    import pssr2_amd.engine as E
+    g = golden("model.npz")
+    target = torch.tensor(g["tiny_target"]).cuda()
+
+    def grads(materialise, xcol_side):
+        monkeypatch.setattr(E, "_NO_MATERIALISE", not materialise)
+        monkeypatch.setattr(E, "_XCOL_SIDE", xcol_side)
+        model, x = _load(g, "tiny")
+        model.compute_dtype = torch.bfloat16
+        model.train()
+        out = []
+        for _ in range(2):                                   # twice: the second pass reuses the materialised buffers
+            for p in model.parameters():
+                p.grad = None
+            torch.nn.functional.mse_loss(model(x) / 255, target / 255).backward()
+            torch.cuda.synchronize()
+            out.append({n: p.grad.clone() for n, p in model.named_parameters()})
+        used = any(getattr(b, "act", None) is not None for b in list(model._engine.plans.values())[-1].enc)
+        return out, used
+    base, used0 = grads(False, False)
+    alt, used1 = grads(True, True)
+    assert not used0 and used1
+    for a, b in zip(base, alt):
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
