@@ -86,3 +86,22 @@ def test_rccl_two_devices(mode):
     """The same three checks over the ``nccl`` backend (= RCCL over xGMI), one rank per device.  Skipped on the 1-GPU test boxes; the
     8-GPU node of the scaling run is where this transport first executes."""
     _run(mode, backend="nccl")
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """``python bench.py --gpus 2`` with no launcher around it: it starts the two ranks as a child
+    torch.distributed.run, rank 0's single JSON line says n_gpus 2 / dp2 and carries the ``comm`` object with both ranks.  Rehearsed
+    here with two gloo ranks on the one card (PSSR_BENCH_FORCE_DEVICE: without it fewer than 2 devices is exit code 2,
+    tests/test_bench_cli.py); on a node the same path runs one rank per GPU over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PSSR_BENCH_FORCE_DEVICE="0", PSSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--tiles", "256",
+                        "--no-cpu-baseline", "--no-extras", "--tile-workers", "4"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64 and d["scaling"] == "weak"
+    assert sorted(x[0] for x in d["comm"]["ranks_seen"]) == [0, 1] and d["comm"]["split_graph"] is True
+    assert d["value"] > 0 and d["steps"] == 4
