@@ -441,6 +441,16 @@ int pssr_input_patchify(const float* x_nchw, void* xpatch, int n, int c, int h, 
  * (pssr_dwconv7_wgrad_workspace_bytes), added to dw in a fixed order: reproducible bit for bit, and not bound by the
  * L2 atomic rate (2.7 M atomics on 21 k addresses cost ~150 us whatever the map size). */
 int pssr_dwconv7_pack(const float* w, float* packed, int c, int flip, pssr_stream_t stream);
+/* pssr_dwconv7_pack of up to PSSR_DWPACK_BATCH_MAX weights by one launch (every block's forward and 180-degree-rotated copy: the
+ * depthwise weights of pssr/models/rdnet.py:71-73 change once per optimizer step). */
+#define PSSR_DWPACK_BATCH_MAX 48
+typedef struct pssr_dwpack_batch {
+    const float* w[PSSR_DWPACK_BATCH_MAX];
+    float* packed[PSSR_DWPACK_BATCH_MAX];
+    int32_t c[PSSR_DWPACK_BATCH_MAX];
+    int32_t flip[PSSR_DWPACK_BATCH_MAX];
+} pssr_dwpack_batch;
+int pssr_dwconv7_pack_batch(const pssr_dwpack_batch* items, int n_items, pssr_stream_t stream);
 int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, const float* bias, void* out, int out_cs,
                  int out_co, int n, int h, int w, int c, int accumulate, int dtype, pssr_stream_t stream);
 int pssr_dwconv7_wgrad(const void* dy, int dy_cs, int dy_co, const void* x, int x_cs, int x_co, float* dw, int n, int h,
@@ -462,12 +472,11 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
                          const float* gamma, const float* mean, const float* rstd, void* dx, int dx_cs, int dx_co,
                          int accumulate, int n, int h, int w, int c, double* stats, int dtype, pssr_stream_t stream);
 /* out[img][c] += scale * sum_{pixels of img} a*b (b may be NULL: plain sum): the spatial mean of timm's
- * EffectiveSEModule (x.mean((2,3))) and the per-image reductions of its backward.  f32 atomics, caller zeroes. */
+ * EffectiveSEModule (x.mean((2,3))) and the per-image reductions of its backward.  One workgroup per (image, 32 channels) sums all the
+ * image's pixels in a fixed order: the same bits on every run, nothing but `out` written. */
 int pssr_image_channel_dot(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c,
                            float scale, float* out, int dtype, pssr_stream_t stream);
-/* The same with run-to-run identical bits: the workgroups of an image leave their partial sums in `workspace`
- * (pssr_image_channel_dot_workspace_bytes; its last n words are tickets: zero before the first use, left zero by every call) and the last
- * one to arrive adds them to `out` in a fixed order.  One call at a time per workspace.  workspace == NULL: the atomic version. */
+/* Entry points of the earlier version that met through a workspace: the workspace size is now 0 and `workspace` is ignored. */
 int64_t pssr_image_channel_dot_workspace_bytes(int n, int hw, int c);
 int pssr_image_channel_dot_ws(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c,
                               float scale, float* out, int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t stream);

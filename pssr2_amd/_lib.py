@@ -66,6 +66,15 @@ class FoldBatch(C.Structure):
     _fields_ = [("dst", C.c_void_p * 16), ("src", C.c_void_p * 16), ("n", C.c_int32 * 16), ("accumulate", C.c_int32 * 16)]
 
 
+DWPACK_BATCH_MAX = 48
+
+
+class DwPackBatch(C.Structure):
+    """struct pssr_dwpack_batch"""
+    _fields_ = [("w", C.c_void_p * DWPACK_BATCH_MAX), ("packed", C.c_void_p * DWPACK_BATCH_MAX), ("c", C.c_int32 * DWPACK_BATCH_MAX),
+                ("flip", C.c_int32 * DWPACK_BATCH_MAX)]
+
+
 class CopyBatch(C.Structure):
     """struct pssr_copy_batch (include/pssr_mi355.h)."""
     _fields_ = [("dst", C.c_void_p * COPY_BATCH_MAX), ("src", C.c_void_p * COPY_BATCH_MAX), ("n", C.c_int64 * COPY_BATCH_MAX)]

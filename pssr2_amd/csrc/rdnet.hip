@@ -58,6 +58,20 @@ __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
+// every depthwise weight of a model (both orientations) by one launch, blockIdx.y = item: RDNet packed 42 of them per training step,
+// each a launch of its own at the head of a dependent chain
+__global__ void dw_pack_batch_kernel(pssr_dwpack_batch items) {
+    const int it = blockIdx.y;
+    const float* __restrict__ w = items.w[it];
+    float* __restrict__ wp = items.packed[it];
+    const int c = items.c[it], flip = items.flip[it];
+    const int total = 49 * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = i % c, tap = i / c;
+        wp[i] = w[ch * 49 + (flip ? 48 - tap : tap)];
+    }
+}
+
 // depthwise 7x7, stride 1, zero padding 3: out[p, c] (+)= bias[c] + sum_tap in[p + tap - 3, c] * wp[tap][c]
 template <typename T>
 __global__ void dwconv7_kernel(Ref in, const float* __restrict__ wp, const float* __restrict__ bias, MRef out, int n, int h, int w, int c,
@@ -646,70 +660,71 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Re
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[img][c] += scale * sum_{p in img} a[p, c] * (b ? b[p, c] : 1);  grid = (chunks, images)
-// With `part` (workspace [images][gridDim.x][c] + one ticket word per image behind it) the workgroups of an image store their partial
-// sums instead of adding them atomically, and the one that draws the last ticket adds them to `out` in workgroup order: the same bits
-// on every run.  The ticket words are zero before and after the launch.
+// out[img][c] += scale * sum_{p in img} a[p, c] * (b ? b[p, c] : 1);  grid = (32-channel slabs, images), 1024 threads
+// A workgroup owns ALL pixels of one image for 32 channels (8 four-channel lanes x 128 pixel lanes, four pixels per trip in flight per
+// thread) and sums its 128 pixel lanes through LDS in a fixed tree: no partial sums in memory, no atomics, the same bits on every run.
+// (The version before split an image's pixels over up to 64 workgroups that met through a workspace, `__threadfence()` and a ticket:
+// on this part an agent-scope release is an L2 write-back per workgroup, and the launch took ~2.5 us per workgroup of an image --
+// 101 us for the 33 MB of a 64^2 x 64-channel layer.)
+constexpr int ICD_T = 1024;
 template <typename T>
-__global__ void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scale, float* __restrict__ out, float* __restrict__ part) {
-    __shared__ float lds[TPB * 4];
-    __shared__ int last_flag;
-    const int cgc = c / 4, img = blockIdx.y;
-    const int ppb = cgc <= TPB ? TPB / cgc : 1;
+__global__ __launch_bounds__(ICD_T) void image_channel_dot_kernel(Ref a, Ref b, int hw, int c, float scale, float* __restrict__ out) {
+    __shared__ float red[ICD_T * 4];
+    const int tid = threadIdx.x, q = tid & 7, pl = tid >> 3, img = blockIdx.y;
+    const int c0 = blockIdx.x * 32 + q * 4;
+    const bool active = c0 < c;
     const long base = (long)img * hw;
-    for (int cg0 = 0; cg0 < cgc; cg0 += TPB) {
-        const int cg = cg0 + (cgc <= TPB ? (int)threadIdx.x % cgc : (int)threadIdx.x);
-        const int pl = cgc <= TPB ? (int)threadIdx.x / cgc : 0;
-        const bool active = cg < cgc && pl < ppb;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (active)
-            for (int p = blockIdx.x * ppb + pl; p < hw; p += gridDim.x * ppb) {
-                float av[4];
-                load4(at<T>(a, base + p, cg * 4), av);
-                if (b.p) {
-                    float bv[4];
-                    load4(at<T>(b, base + p, cg * 4), bv);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        constexpr int PL = ICD_T / 8;
+        int p = pl;
+        for (; p + 3 * PL < hw; p += 4 * PL) {
+            float av[4][4], bv[4][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[e], bv[e], acc[e]);
-                } else {
+            for (int u = 0; u < 4; ++u) load4(at<T>(a, base + p + u * PL, c0), av[u]);
+            if (b.p) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += av[e];
-                }
+                for (int u = 0; u < 4; ++u) load4(at<T>(b, base + p + u * PL, c0), bv[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[u][e], bv[u][e], acc[e]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += av[u][e];
             }
+        }
+        for (; p < hw; p += PL) {
+            float av[4];
+            load4(at<T>(a, base + p, c0), av);
+            if (b.p) {
+                float bv[4];
+                load4(at<T>(b, base + p, c0), bv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lds[threadIdx.x * 4 + e] = active ? acc[e] : 0.f;
-        __syncthreads();
-        if (cgc <= TPB) {
-            if ((int)threadIdx.x < cgc)
-                for (int e = 0; e < 4; ++e) {
-                    float t = 0.f;
-                    for (int q = 0; q < ppb; ++q) t += lds[(q * cgc + threadIdx.x) * 4 + e];
-                    if (part) part[((long)img * gridDim.x + blockIdx.x) * c + threadIdx.x * 4 + e] = t * scale;
-                    else atomicAdd(out + (long)img * c + threadIdx.x * 4 + e, t * scale);
-                }
-        } else if (active) {
-            for (int e = 0; e < 4; ++e) {
-                if (part) part[((long)img * gridDim.x + blockIdx.x) * c + cg * 4 + e] = acc[e] * scale;
-                else atomicAdd(out + (long)img * c + cg * 4 + e, acc[e] * scale);
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[e], bv[e], acc[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += av[e];
             }
+        }
+    }
+    *(float4*)(red + tid * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+#pragma unroll
+    for (int s = ICD_T / 16; s >= 1; s >>= 1) {         // pixel lanes pl and pl + s: thread tid + 8 s
+        if (pl < s) {
+            const float4 x = *(const float4*)(red + tid * 4), y = *(const float4*)(red + (tid + 8 * s) * 4);
+            *(float4*)(red + tid * 4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
         }
         __syncthreads();
     }
-    if (!part) return;
-    unsigned* tickets = (unsigned*)(part + (long)gridDim.y * gridDim.x * c);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last_flag = atomicAdd(tickets + img, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
-    for (int ch = threadIdx.x; ch < c; ch += TPB) {
-        float t = 0.f;
-        for (unsigned k = 0; k < gridDim.x; ++k)
-            t += __hip_atomic_load(part + ((long)img * gridDim.x + k) * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[(long)img * c + ch] += t;
+    if (pl == 0 && active) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < c) out[(long)img * c + c0 + e] += red[q * 4 + e] * scale;
     }
-    if (threadIdx.x == 0) tickets[img] = 0u;
 }
 
 // Effective-SE gate: u[n][co] = b[co] + sum_ci W[co][ci] * s[n][ci];  gate = relu6(u + 3) / 6
@@ -905,6 +920,18 @@ int pssr_dwconv7_pack(const float* w, float* packed, int c, int flip, pssr_strea
     return PSSR_OK;
 }
 
+int pssr_dwconv7_pack_batch(const pssr_dwpack_batch* items, int n_items, pssr_stream_t s) {
+    PSSR_CHECK(items && n_items > 0 && n_items <= PSSR_DWPACK_BATCH_MAX, PSSR_ERR_ARG, "dwconv7_pack_batch: 1..%d items", PSSR_DWPACK_BATCH_MAX);
+    int cmax = 0;
+    for (int i = 0; i < n_items; ++i) {
+        PSSR_CHECK(items->w[i] && items->packed[i] && items->c[i] > 0, PSSR_ERR_ARG, "dwconv7_pack_batch: item %d", i);
+        if (items->c[i] > cmax) cmax = items->c[i];
+    }
+    hipLaunchKernelGGL(dw_pack_batch_kernel, dim3(grid1d(49L * cmax, 16), n_items), dim3(TPB), 0, (hipStream_t)s, *items);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
 int pssr_dwconv7(const void* in, int in_cs, int in_co, const float* w_packed, const float* bias, void* out, int out_cs, int out_co,
                  int n, int h, int w, int c, int accumulate, int dtype, pssr_stream_t s) {
     PSSR_CHECK(in && w_packed && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "dwconv7: bad args");
@@ -1039,26 +1066,19 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
     return PSSR_OK;
 }
 
-static int icd_chunks(int hw, int c) {
-    const int cgc = c / 4, ppb = cgc <= TPB ? TPB / cgc : 1;
-    int gx = (hw + ppb - 1) / ppb / 8;
-    return gx < 1 ? 1 : gx > 64 ? 64 : gx;
-}
-
 int64_t pssr_image_channel_dot_workspace_bytes(int n, int hw, int c) {
     if (n <= 0 || hw <= 0 || c <= 0) return PSSR_ERR_ARG;
-    return ((int64_t)n * icd_chunks(hw, c) * c + n) * 4;
+    return 0;           // kept for callers of the ticket version: the slab kernel needs no workspace
 }
 
 int pssr_image_channel_dot_ws(const void* a, int a_cs, int a_co, const void* b, int b_cs, int b_co, int n, int hw, int c, float scale, float* out,
                               int dtype, void* workspace, int64_t workspace_bytes, pssr_stream_t s) {
+    (void)workspace; (void)workspace_bytes;
     PSSR_CHECK(a && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0, PSSR_ERR_ARG, "image_channel_dot: bad args");
     CHECK_REF("image_channel_dot a", a_cs, a_co, c);
     if (b) CHECK_REF("image_channel_dot b", b_cs, b_co, c);
-    PSSR_CHECK(!workspace || workspace_bytes >= pssr_image_channel_dot_workspace_bytes(n, hw, c), PSSR_ERR_ARG, "image_channel_dot: workspace too small");
-    const int gx = icd_chunks(hw, c);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(image_channel_dot_kernel<T>, dim3(gx, n), dim3(TPB), 0, (hipStream_t)s, Ref{a, a_cs, a_co}, Ref{b, b_cs, b_co},
-                                         hw, c, scale, out, (float*)workspace));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(image_channel_dot_kernel<T>, dim3(cdiv(c, 32), n), dim3(ICD_T), 0, (hipStream_t)s, Ref{a, a_cs, a_co},
+                                         Ref{b, b_cs, b_co}, hw, c, scale, out));
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

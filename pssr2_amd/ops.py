@@ -387,6 +387,20 @@ def input_norm_bwd2(dxcol_a, dxcol_b, dpatch, patch, x, mean, invstd, stats, dty
                                          L.stream_ptr()), "pssr_input_norm_bwd2")
 
 
+def dwconv7_pack_batch(items):
+    """[(weight [C,1,7,7] f32, packed [49, C] f32, flip), ...] by one launch per 48 items (pssr_dwconv7_pack_batch)."""
+    for k in range(0, len(items), L.DWPACK_BATCH_MAX):
+        chunk = items[k:k + L.DWPACK_BATCH_MAX]
+        b = L.DwPackBatch()
+        for i, (w, out, flip) in enumerate(chunk):
+            c = w.shape[0]
+            if w.dtype != torch.float32 or out.dtype != torch.float32 or not (w.is_contiguous() and out.is_contiguous()) or w.numel() != 49 * c \
+                    or out.numel() < 49 * c:
+                raise ValueError("dwconv7_pack_batch needs contiguous float32 [C,1,7,7] weights and [49, C] destinations")
+            b.w[i], b.packed[i], b.c[i], b.flip[i] = w.data_ptr(), out.data_ptr(), c, int(flip)
+        L.check(L.lib().pssr_dwconv7_pack_batch(C.byref(b), len(chunk), L.stream_ptr()), "pssr_dwconv7_pack_batch")
+
+
 def dwconv7_pack(w, out, flip=False):
     """torch depthwise weight [C,1,7,7] f32 -> [49][C] f32 (flip: rotated 180 degrees for the input gradient)."""
     c = w.shape[0]
@@ -425,25 +439,12 @@ def layernorm2d_bwd(g, x, gamma, mean, rstd, dx, stats, n, h, w, c, dtype, g_cof
             "pssr_layernorm2d_bwd")
 
 
-_ICD_WS = {}
-
-
 def image_channel_dot(a, b, n, hw, c, scale, out, dtype, a_coff=0, b_coff=0):
-    """out[img][c] += scale * sum over the image's pixels of a * b, the same bits on every run (fixed-order partial sums through a
-    workspace kept per (device, size): the engines issue these calls on the launch stream only, so they are ordered, and the library
-    leaves its ticket words zero)."""
+    """out[img][c] += scale * sum over the image's pixels of a * b, the same bits on every run (one workgroup per image and 32 channels,
+    fixed summation order)."""
     bref = _ref(b, b_coff) if b is not None else (None, 0, 0)
-    lib = L.lib()
-    lib.pssr_image_channel_dot_workspace_bytes.restype = C.c_int64
-    need = lib.pssr_image_channel_dot_workspace_bytes(n, hw, c)
-    key = (out.device, need)
-    ws = _ICD_WS.get(key)
-    if ws is None:
-        ws = torch.zeros(need, dtype=torch.uint8, device=out.device)
-        if not torch.cuda.is_current_stream_capturing():    # (a first use inside a capture gets a one-off buffer of the capture's pool)
-            _ICD_WS[key] = ws
-    L.check(lib.pssr_image_channel_dot_ws(*_ref(a, a_coff), *bref, n, hw, c, C.c_float(scale), L.ptr(out), dtype, L.ptr(ws), C.c_int64(need),
-                                          L.stream_ptr()), "pssr_image_channel_dot_ws")
+    L.check(L.lib().pssr_image_channel_dot(*_ref(a, a_coff), *bref, n, hw, c, C.c_float(scale), L.ptr(out), dtype, L.stream_ptr()),
+            "pssr_image_channel_dot")
 
 
 def ese_gate(s_mean, w_fc, b_fc, u, gate):

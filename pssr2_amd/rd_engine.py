@@ -325,7 +325,21 @@ class RDEngine(Engine):
         self._fold64(s64, g)
         grads[id(bias)] = g
 
-    def _wgrad1x1(self, p, grads, conv_module, dy, cout, dy_coff, src, cin_pad, hh, ww, *, mode=0, gelu_in=False):
+    def _bias_grad_job(self, bw, grads, bias, t, npix, c, code, coff=0):
+        """The same sum as _bias_grad as a closure for the second stream: it rides in front of the weight gradient that reads the same
+        tensor (49 launches of ~11 us that nothing on the dependent chain waits for)."""
+        s64 = self._z64.take(ops.STAT_STRIPES * c, bw.stat_ln)
+        if not self._z64.owns(s64):         # first pass: the arena's fallback buffer is reused by the next request, this sum is read later
+            s64 = torch.zeros(ops.STAT_STRIPES * c, dtype=torch.float64, device=bw.stat_ln.device)
+        g = self._gbuf(bias)
+        grads[id(bias)] = g
+
+        def run():
+            ops.channel_sum_nhwc(t, npix, c, s64, code, coff=coff)
+            ops.f64_to_f32(s64, g)
+        return run
+
+    def _wgrad1x1(self, p, grads, conv_module, dy, cout, dy_coff, src, cin_pad, hh, ww, *, mode=0, gelu_in=False, first=None):
         code = p.code
         esz = 4 if code == L.F32 else 2
         rows = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
@@ -333,6 +347,8 @@ class RDEngine(Engine):
         slot = grads[id(w)] = self._gbuf(w)
 
         def run():
+            if first is not None:
+                first()
             dwp = ops.conv2d_wgrad_parts(dy, rows, src, cin_pad, 1, n=p.n, h=hh, w=ww, dtype=code, dy_coff=dy_coff, gelu_in=gelu_in)
             ops.unpack_conv_wgrad(dwp, slot, mode=mode, k_pad=cin_pad, accumulate=True)     # slot zeroed at the start of backward
         if self._side_on:
@@ -375,7 +391,15 @@ class RDEngine(Engine):
         ops.conv2d(p.xpatch, self.pc, self._pw(stem_conv, "fwd", code, mode=2), p.stem_y, c0, n=n, h=st0.h, w=st0.w, bias=stem_conv.bias)
         ops.layernorm2d_fwd(p.stem_y, stem_ln.weight, stem_ln.bias, LN_EPS, st0.F, n, st0.h, st0.w, c0, code, out_coff=st0.coff, c_pad=c0,
                             mean=p.stem_stat[0] if train else None, rstd=p.stem_stat[1] if train else None)
-        # ---- dense stages
+        # ---- dense stages (every depthwise weight, and its rotated copy for the backward pass, packed by one launch)
+        dw_items = []
+        for st in p.stages:
+            for bk in st.blocks:
+                dww = bk.mod.layers.layers[0].weight
+                dw_items.append((dww, bk.wp, False))
+                if train:
+                    dw_items.append((dww, bk.wpf, True))
+        ops.dwconv7_pack_batch(dw_items)
         for i, st in enumerate(p.stages):
             if i:
                 prev = p.stages[i - 1]
@@ -388,7 +412,6 @@ class RDEngine(Engine):
             for bk in st.blocks:
                 lay = bk.mod.layers.layers
                 dwc, ln, c1, c2 = lay[0], lay[1], lay[2], lay[4]
-                ops.dwconv7_pack(dwc.weight, bk.wp)
                 ops.dwconv7(st.F, bk.wp, dwc.bias, bk.dw, n, st.h, st.w, bk.c_in, code, in_coff=st.coff)
                 ops.layernorm2d_fwd(bk.dw, ln.weight, ln.bias, LN_EPS, bk.ln, n, st.h, st.w, bk.c_in, code,
                                     mean=bk.stat[0] if train else None, rstd=bk.stat[1] if train else None)
@@ -449,8 +472,8 @@ class RDEngine(Engine):
             ops.scale_nc(G, None, bk.mod.gamma, None, sc.dt, n, hw, g, code, t_coff=gcoff + bk.off)
         grads[id(bk.mod.gamma)] = dgam
         # ---- second 1x1 conv (input = gelu(z))
-        self._bias_grad(bw, grads, c2.bias, sc.dt, st.npix, g, code)
-        self._wgrad1x1(p, grads, c2, sc.dt, g, 0, bk.z, bk.inter, st.h, st.w, gelu_in=True)
+        self._wgrad1x1(p, grads, c2, sc.dt, g, 0, bk.z, bk.inter, st.h, st.w, gelu_in=True,
+                       first=self._bias_grad_job(bw, grads, c2.bias, sc.dt, st.npix, g, code))
         s64 = self._z64.take(ops.STAT_STRIPES * 2 * bk.inter, bw.stat_ln)
         self._before_write(sc.dz)
         ops.conv2d(sc.dt, sc.dt.shape[-1], self._pw(c2, "dgrad", code, mode=1), sc.dz, bk.inter, n=n, h=st.h, w=st.w,
@@ -468,18 +491,18 @@ class RDEngine(Engine):
         ops.layernorm2d_bwd(sc.dln, bk.dw, ln.weight, bk.stat[0], bk.stat[1], sc.ddw, s64, n, st.h, st.w, bk.c_in, code, c_pad=bk.c_in)
         self._ln_grads(bw, grads, ln, bk.c_in, s64)
         # ---- depthwise 7x7
-        self._bias_grad(bw, grads, dwc.bias, sc.ddw, st.npix, bk.c_in, code)
+        dwb_run = self._bias_grad_job(bw, grads, dwc.bias, sc.ddw, st.npix, bk.c_in, code)
         dww = self._gbuf(dwc.weight)
         ddw, c_in = sc.ddw, bk.c_in
 
         def dw_run():
+            dwb_run()
             ops.dwconv7_wgrad(ddw, st.F, dww.view(c_in, 49), n, st.h, st.w, c_in, code, x_coff=st.coff)
         if self._side_on:
             self._on_side([ddw], dw_run)
         else:
             dw_run()
         grads[id(dwc.weight)] = dww
-        ops.dwconv7_pack(dwc.weight, bk.wpf, flip=True)
         ops.dwconv7(sc.ddw, bk.wpf, None, G, n, st.h, st.w, bk.c_in, code, out_coff=gcoff, accumulate=True)
         self._ready(grads, list(bk.mod.parameters()))
 
@@ -541,8 +564,8 @@ class RDEngine(Engine):
                 seq = enc.dense_stages[i]
                 ln, conv = seq[0], seq[1]
                 kc = st.tr_ln.shape[-1]
-                self._bias_grad(bw, grads, conv.bias, G, st.npix, st.c_in, code, coff=gcoff)
-                self._wgrad1x1(p, grads, conv, G, st.c_in, gcoff, st.tr_ln, kc, st.h, st.w, mode=4 if st.ds else 0)
+                self._wgrad1x1(p, grads, conv, G, st.c_in, gcoff, st.tr_ln, kc, st.h, st.w, mode=4 if st.ds else 0,
+                               first=self._bias_grad_job(bw, grads, conv.bias, G, st.npix, st.c_in, code, coff=gcoff))
                 # the dgrad reads the first c_in channels of G at its offset (K padded to 16: the packed weight rows beyond
                 # c_in are zero and the gradient buffer holds finite values there)
                 ops.conv2d(G, ops.pad_to(st.c_in, 16), self._pw(conv, "dgrad", code, mode=5 if st.ds else 1), sc.dtr, kc,
