@@ -160,8 +160,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
                 } else if (p.epi == PSSR_EPI_DGRAD_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(a[e]);
+                    gelu_grad_mul_vec<T, 4>(a, v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -305,11 +304,12 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
                 const u32x4 araw = *(const u32x4*)(auxp + pix_index(gi, gy, gx, p.H, p.W, p.aux_blk) * p.aux_cs);
                 X::unpack(araw, a);
             }
+            if constexpr (EPI == PSSR_EPI_DGRAD_GELU) gelu_grad_mul_vec<T, 8>(a, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (EPI == PSSR_EPI_STORE) v[e] = fmaxf(v[e] + bias[e], relu_lo);
                 else if (EPI == PSSR_EPI_TAIL) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
-                else if (EPI == PSSR_EPI_DGRAD_GELU) v[e] *= gelu_grad_t<T>(a[e]);
+                else if (EPI == PSSR_EPI_DGRAD_GELU) {}
                 else {
                     v[e] = (fmaf(a[e], xs[e], xh[e]) > 0.f) ? v[e] : 0.f;
                     a[e] = (a[e] - xm[e]) * xi[e];       // xhat
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     if (gelu_) {      /* gelu(0) == 0: padding stays zero */                                      \
                         float f[EPS];                                                                             \
                         X::unpack(v, f);                                                                          \
-                        _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                      \
+                        gelu_vec<T, EPS>(f);                      \
                         v = X::pack(f);                                                                           \
                     }                                                                                             \
                     *(u32x4*)(As + a_lds[it]) = v;                                                                \
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC <= 4 ? 3
             if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                            \
                 float f[EPS];                                                                                     \
                 X::unpack(v, f);                                                                                  \
-                _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                              \
+                gelu_vec<T, EPS>(f);                              \
                 v = X::pack(f);                                                                                   \
             }                                                                                                     \
             *(u32x4*)(As + it * 4096 + a_lds) = v;                                                                \

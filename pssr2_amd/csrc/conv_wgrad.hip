@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && GEO < 2) ? 2 : 1) void conv
                 } else if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                 \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
+                    gelu_vec<T, EPS>(f);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(Ah + sub * HP * ROWB + pp * ROWB + pin * 16) = v;                                       \
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const WgradArgs p)
                 } else if (p.prologue == PSSR_PRO_GELU) {      /* gelu(0) == 0 */                                 \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
+                    gelu_vec<T, EPS>(f);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(Ah + ah_lds + it * (256 / AH_PPP) * ROWB) = v;                                          \
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad16x2_kernel(const WgradArgs 
                 } else if (p.prologue == PSSR_PRO_GELU) {                                                         \
                     float f[EPS];                                                                                 \
                     X::unpack(v, f);                                                                              \
-                    _Pragma("unroll") for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);                          \
+                    gelu_vec<T, EPS>(f);                          \
                     v = X::pack(f);                                                                               \
                 }                                                                                                 \
                 *(u32x4*)(Ah + ah_lds + it * (256 / AH_PPP) * ROWB) = v;                                          \
@@ -1042,8 +1042,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_1x1_kernel(const WgradArg
             else if (p.prologue == PSSR_PRO_GELU) {
                 float f[EPS];
                 X::unpack(v, f);
-#pragma unroll
-                for (int e = 0; e < EPS; ++e) f[e] = gelu_t<T>(f[e]);
+                gelu_vec<T, EPS>(f);
                 v = X::pack(f);
             }
             *(u32x4*)(Xt + lds0 + it * 16 * ROWB) = v;
