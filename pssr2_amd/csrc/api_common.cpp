@@ -40,6 +40,9 @@ const Entry kEntries[] = {
     {"WGRAD_BLOCKS_1X1", &PssrTunables::wgrad_blocks_1x1, 512, 1, 1 << 20},
     {"DWCONV_TILE", &PssrTunables::dwconv_tile, 1, 0, 1},
     {"DWWG_BLOCKS", &PssrTunables::dwwg_blocks, 1024, 1, 1 << 20},
+    {"LN_BWD_BLOCKS", &PssrTunables::ln_bwd_blocks, 256, 1, 1 << 20},
+    {"LN_BWD_PP", &PssrTunables::ln_bwd_pp, 1, 1, 4},
+    {"LN_DBG", &PssrTunables::ln_dbg, 0, 0, 3},
 };
 PssrTunables g_tun;
 std::once_flag g_tun_once;

@@ -170,8 +170,9 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 // Horner chains: no wait states between the dependent FMAs):
 //   gelu(z)  = max(z, 0) - u T(s),          T = 1 - Phi on [0, 5]
 //   gelu'(z) = 1/2 + sign(z) D(s),          D = Phi - 1/2 + u phi on [0, 5]
-// Least-squares Chebyshev fits on 400 k points, Horner in f32; beyond |z| = 5 both are their limits to 2e-6.  fp16 storage: degree 12
-// (|error| of u T <= 7e-6, of D <= 5e-5); bf16 storage: degree 10 (1.3e-4 / 3.3e-4, 1/30 of a bf16 step at 1).  The
+// Least-squares Chebyshev fits on 400 k points, Horner in f32; beyond |z| = 5 both are their limits to 2e-6.  Degree 12
+// (|error| of u T <= 7e-6, of D <= 5e-5) for both storage types (degree 10 -- 1.3e-4 / 3.3e-4 -- is 8 % cheaper and moved the bf16
+// gradients of tests/test_gpu_atrous.py's untrained RD net measurably).  The
 // Abramowitz-Stegun 7.1.26 form used before (v_rcp + v_exp + 15 more instructions per value) cost twice as much, and RDNet's 1x1
 // layers apply GELU or its derivative to every element of the 4C-wide tensor three times per step: conv2's forward and
 // weight-gradient kernels ran 45 % faster with the GELU left out, its input gradient 15 %.  The exact-f32 build keeps erff.
@@ -188,13 +189,7 @@ template <> struct GeluPoly<f16_t> {
                                      -2.109314755e-01f, -1.116054970e+00f, 8.931616973e-01f, 3.827852021e-01f, -5.670671519e-01f, -3.991985896e-02f,
                                      1.278773880e-01f};
 };
-template <> struct GeluPoly<bf16_t> {
-    static constexpr int DEG = 10;
-    static constexpr float CT[11] = {6.213969994e-03f, -4.371224877e-02f, 1.365927538e-01f, -2.419721427e-01f, 2.363407950e-01f, -5.142805568e-02f,
-                                     -1.473795865e-01f, 1.290900546e-01f, 8.451452832e-03f, -4.201739979e-02f, 9.796322409e-03f};
-    static constexpr float CD[11] = {5.375642628e-01f, -1.864208519e-01f, 3.118492297e-01f, 3.396259326e-02f, -8.816745394e-01f, 1.141378700e+00f,
-                                     -1.779568154e-02f, -1.017004705e+00f, 4.999943681e-01f, 2.782326678e-01f, -2.001128126e-01f};
-};
+template <> struct GeluPoly<bf16_t> : GeluPoly<f16_t> {};
 // t[p] = poly(s[p]) for NP pairs, the chains interleaved
 template <typename T, int WHICH, int NP> __device__ __forceinline__ void gelu_poly_pairs(const pssr_v2f (&sv)[NP], pssr_v2f (&t)[NP]) {
     using G = GeluPoly<T>;

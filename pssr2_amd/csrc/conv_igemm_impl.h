@@ -790,15 +790,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC <= 4 ? 3
             for (int mi = 0; mi < C::MI; ++mi) af[mi] = *(const u32x4*)(As + t * 4096 + a_rd[mi]);
 #pragma unroll
             for (int nj = 0; nj < C::NJ; ++nj) bf[nj] = *(const u32x4*)(Bs + t * BN * 32 + b_off[nj]);
+            if (!(p.dbg & 2)) {          // (diagnostic bit 2: no multiplies)
 #pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi)
+                for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);
+                    for (int nj = 0; nj < C::NJ; ++nj) X::mma(acc[mi][nj], af[mi], bf[nj]);
+            }
         }
         __syncthreads();
     }
 #undef PF_ISSUE
 #undef PF_COMMIT
+    if (p.dbg & 1) return;               // (diagnostic bit 1: no epilogue)
     if (p.ksplit > 1) {
         float4* dst = (float4*)p.ws + ((long)blockIdx.x * p.ksplit + blockIdx.y) * (4 * C::MI * C::NJ) * 256 + tid;
 #pragma unroll

@@ -581,60 +581,98 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(Ref in, const float* __rest
 // dx (+)= rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat));  stats += [sum_p g*xhat | sum_p g]
 // NIT = channel slices of 256 a lane walks (registers scale with it), NT = threads: few slices leave room for 16 waves per
 // workgroup, which share one flush of the statistics (the f64 atomics bound how many workgroups a launch can afford)
-template <typename T, int NIT, int NT>
+// PP = pixels a wave has in flight per trip (their loads issued together, their reductions independent).  Measured
+// (tools/diag/microbench_ln.py): PP = 2 / 4 change nothing -- what a launch pays besides its bytes is the statistics flush at the end,
+// 2c f64 atomic pairs per workgroup (10-20 us for 256-512 workgroups: PSSR_LN_DBG=1 leaves it out), so the default stays 1
+template <typename T, int NIT, int NT, int PP>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __restrict__ gamma, const float* __restrict__ mean,
-                              const float* __restrict__ rstd, MRef dx, int accumulate, long npix, int h, int w, int c, double* stats) {
+                              const float* __restrict__ rstd, MRef dx, int accumulate, long npix, int h, int w, int c, double* stats, int dbg) {
     __shared__ float lds[(NT / 64) * 64 * 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long wid = (long)blockIdx.x * (NT / 64) + wv, nw = (long)gridDim.x * (NT / 64);
     const float inv_c = 1.f / (float)c;
+    if (dbg & 2) npix = 0;          // (diagnostic: no pixels)
     float dgam[NIT][4], dbet[NIT][4];
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dgam[it][e] = dbet[it][e] = 0.f;
-    for (long pix = wid; pix < npix; pix += nw) {
-        const float mu = mean[pix], rs = rstd[pix];
-        long opix; int cbase;
-        ln_out_pos(pix, h, w, s2d, cpad, opix, cbase);
-        float xh[NIT][4], gg[NIT][4];
-        float s1 = 0.f, s2 = 0.f;
+    float gm[NIT][4];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c0 = (lane + 64 * it) * 4;
-            if (c0 < c) {
-                float xv[4], gv[4], gm[4];
-                load4(at<T>(x, pix, c0), xv); load4(at<T>(g, opix, cbase + c0), gv); load4(gamma + c0, gm);
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (lane + 64 * it) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[it][e] = (xv[e] - mu) * rs;
-                    gg[it][e] = gv[e] * gm[e];
-                    s1 += gg[it][e];
-                    s2 = fmaf(gg[it][e], xh[it][e], s2);
-                    dgam[it][e] = fmaf(gv[e], xh[it][e], dgam[it][e]);
-                    dbet[it][e] += gv[e];
+        for (int e = 0; e < 4; ++e) gm[it][e] = 0.f;
+        if (c0 < c) load4(gamma + c0, gm[it]);
+    }
+    for (long pix0 = wid; pix0 < npix; pix0 += nw * PP) {
+        float xh[PP][NIT][4], gg[PP][NIT][4], gv[PP][NIT][4];
+        float mu[PP], rs[PP], s1[PP], s2[PP];
+        bool ok[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const long pix = pix0 + u * nw;
+            ok[u] = pix < npix;
+            mu[u] = ok[u] ? mean[pix] : 0.f;
+            rs[u] = ok[u] ? rstd[pix] : 0.f;
+            long opix = 0; int cbase = 0;
+            if (ok[u]) ln_out_pos(pix, h, w, s2d, cpad, opix, cbase);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c0 = (lane + 64 * it) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xh[u][it][e] = 0.f; gv[u][it][e] = 0.f; }
+                if (ok[u] && c0 < c) { load4(at<T>(x, pix, c0), xh[u][it]); load4(at<T>(g, opix, cbase + c0), gv[u][it]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c0 = (lane + 64 * it) * 4;
+                if (c0 < c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xh[u][it][e] = (xh[u][it][e] - mu[u]) * rs[u];
+                        gg[u][it][e] = gv[u][it][e] * gm[it][e];
+                        s1[u] += gg[u][it][e];
+                        s2[u] = fmaf(gg[u][it][e], xh[u][it][e], s2[u]);
+                        if (ok[u]) {
+                            dgam[it][e] = fmaf(gv[u][it][e], xh[u][it][e], dgam[it][e]);
+                            dbet[it][e] += gv[u][it][e];
+                        }
+                    }
                 }
             }
         }
-        const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
+        float m1[PP], m2[PP];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c0 = (lane + 64 * it) * 4;
-            if (c0 < c) {
-                float o[4];
+        for (int u = 0; u < PP; ++u) { m1[u] = wave_sum(s1[u]) * inv_c; m2[u] = wave_sum(s2[u]) * inv_c; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rs * (gg[it][e] - m1 - xh[it][e] * m2);
-                if (accumulate) {
-                    float prev[4];
-                    load4(at<T>(dx, pix, c0), prev);
+        for (int u = 0; u < PP; ++u) {
+            const long pix = pix0 + u * nw;
+            if (!ok[u]) continue;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += prev[e];
+            for (int it = 0; it < NIT; ++it) {
+                const int c0 = (lane + 64 * it) * 4;
+                if (c0 < c) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rs[u] * (gg[u][it][e] - m1[u] - xh[u][it][e] * m2[u]);
+                    if (accumulate) {
+                        float prev[4];
+                        load4(at<T>(dx, pix, c0), prev);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += prev[e];
+                    }
+                    store4(at<T>(dx, pix, c0), o);
                 }
-                store4(at<T>(dx, pix, c0), o);
             }
         }
     }
     // block combine (4 waves) per iteration slice, then one f64 atomic per channel per block into a stripe
+    if (dbg & 1) return;            // (diagnostic: no statistics)
     double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1049,18 +1087,19 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
     CHECK_REF("layernorm2d_bwd g", g_cs, g_co, (s2d ? 4 : 1) * c_pad); CHECK_REF("layernorm2d_bwd x", x_cs, x_co, c); CHECK_REF("layernorm2d_bwd dx", dx_cs, dx_co, c);
     const long npix = (long)n * h * w;
     // >= 4 pixels per wave before the statistics are flushed, <= 512 workgroups (2c f64 atomics each)
-#define PSSR_LN_BWD(NIT_, NT_)                                                                                                              \
+#define PSSR_LN_BWD(NIT_, NT_, PP_)                                                                                                         \
     do {                                                                                                                                    \
         long blocks = (npix + (NT_) / 64 - 1) / ((NT_) / 64) / 4;                                                                           \
         if (blocks < 1) blocks = 1;                                                                                                         \
-        if (blocks > 512) blocks = 512;                                                                                                     \
-        DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NIT_, NT_>), dim3((unsigned)blocks), dim3(NT_), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, \
-                                             c_pad, Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats)); \
+        if (blocks > pssr_tunables().ln_bwd_blocks) blocks = pssr_tunables().ln_bwd_blocks;                                                 \
+        DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NIT_, NT_, PP_>), dim3((unsigned)blocks), dim3(NT_), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, \
+                                             c_pad, Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats, pssr_tunables().ln_dbg)); \
     } while (0)
-    if (c <= 256) PSSR_LN_BWD(1, 1024);
-    else if (c <= 512) PSSR_LN_BWD(2, 1024);
-    else if (c <= 1024) PSSR_LN_BWD(4, 512);
-    else PSSR_LN_BWD(8, 256);
+    const int pp = pssr_tunables().ln_bwd_pp;
+    if (c <= 256) { if (pp <= 1) PSSR_LN_BWD(1, 1024, 1); else if (pp == 2) PSSR_LN_BWD(1, 1024, 2); else PSSR_LN_BWD(1, 1024, 4); }
+    else if (c <= 512) { if (pp <= 1) PSSR_LN_BWD(2, 1024, 1); else PSSR_LN_BWD(2, 1024, 2); }
+    else if (c <= 1024) { if (pp <= 1) PSSR_LN_BWD(4, 512, 1); else PSSR_LN_BWD(4, 512, 2); }
+    else PSSR_LN_BWD(8, 256, 1);
 #undef PSSR_LN_BWD
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
