@@ -198,6 +198,7 @@ class Engine:
         view of the flat buffer itself (no AccumulateGrad copy, and FusedAdamW / the all-reduce see one flat tensor); an
         existing gradient is accumulated into, as autograd would."""
         self._flush_folds()
+        self._flush_moves()
         if self.reducer is not None:
             self.reducer.finish()
         self._side_join()
@@ -282,6 +283,7 @@ class Engine:
         self._pending = {}
         self._side_on = False
         self.__dict__.get("_folds", []).clear()
+        self.__dict__.get("_moves", []).clear()
 
     def _side_join(self):
         if self._side_on:
@@ -319,9 +321,20 @@ class Engine:
             grads[id(prm)] = self._gviews[i]
             idx.append(i)
         if moves:
-            ops.copy_f32_batch(moves)
+            if self.reducer is None:
+                # nothing reads these slots before the pass ends (or the split callback): one launch there instead of one per block
+                # on the dependent chain
+                self.__dict__.setdefault("_moves", []).extend(moves)
+            else:
+                ops.copy_f32_batch(moves)
         if self.reducer is not None:
             self.reducer.mark_ready(idx)
+
+    def _flush_moves(self):
+        q = self.__dict__.get("_moves")
+        if q:
+            ops.copy_f32_batch(q)
+            q.clear()
 
     # ------------------------------------------------------------------ static structure
     def _structure(self, device):
@@ -944,6 +957,8 @@ class Engine:
                 src, cin, dsrc, dsrc_c = p.pooled[i - 1], ops.pad_to(hid[i - 1], 16), bw.dpooled[i - 1], hid[i - 1]
             self._block_backward(p, bw, grads, blk, m.encoder[i], src, cin, i == 0, out_buf, out_off, bw.dout[i], dsrc, dsrc_c)
             if split_cb is not None and i == Lv - 1 and Lv > 1:
+                self._flush_folds()
+                self._flush_moves()
                 self._side_join()
                 split_cb()
         if self.atrous:                 # no input BatchNorm, and the network input needs no gradient

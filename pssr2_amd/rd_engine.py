@@ -550,6 +550,8 @@ class RDEngine(Engine):
                 self._block_backward(p, bw, grads, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, bw.dout[k], bw.dcat[k],
                                      p.shuf_c[k] + m.skips[k])
         if split_cb is not None:       # reconstruction + decoder gradients (the tail of the flat buffer) are final
+            self._flush_folds()
+            self._flush_moves()
             self._side_join()
             split_cb()
         # ---- encoder, last stage first

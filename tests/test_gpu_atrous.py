@@ -166,6 +166,7 @@ def test_resblocka_block_vs_f64_autograd(cin, c, dils, depth, n, h, w):
     (y * gy.double()).sum().backward()
     dsrc = torch.zeros_like(src)
     A.ablock_backward(eng, st, mod, {}, src, 0, n, L.F32, dst, 0, _nhwc_dev(gy, ops.pad_to(c, 16)), 0, dsrc, True)
+    eng._flush_folds(), eng._flush_moves()          # what the end of a whole backward pass does (Engine._finish_backward)
     torch.cuda.synchronize()
     assert float((dsrc[..., :cin].permute(0, 3, 1, 2).cpu().double() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
     for k, prm in mod.named_parameters():
@@ -200,6 +201,7 @@ def test_psp_block_vs_f64_autograd(C, sizes, n, h, w):
     (y * gy.double()).sum().backward()
     dsrc = torch.zeros_like(src)
     A.psp_backward(eng, st, mod, {}, src, 0, n, L.F32, dst, 0, _nhwc_dev(gy, Cp), 0, dsrc, 0)
+    eng._flush_folds(), eng._flush_moves()
     torch.cuda.synchronize()
     assert float((dsrc[..., :C].permute(0, 3, 1, 2).cpu().double() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
     for k, prm in mod.named_parameters():
