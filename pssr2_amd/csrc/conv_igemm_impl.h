@@ -48,8 +48,14 @@ template <int BN, int GEO> struct Cfg {
     static constexpr int MP = WM * MI * 32;                                   // output pixels per workgroup
     static constexpr int TW = 1 << TWL, TH = 1 << THL, NI = MP >> (TWL + THL);
     static constexpr int HW2 = TW + 2, HPI = (TH + 2) * (TW + 2), HP = NI * HPI;
+    // pitch of a halo row in LDS, in pixels.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and
+    // the same + 32): with the 16-byte halves swizzled by pixel bit 3 a group is conflict-free iff its 16 pixel indices differ mod 16,
+    // and the rows of a tile that share a group are TW apart in x -- with the natural pitch TW + 2 the second row lands two slots into
+    // the first one's (measured 24-38 % conflict cycles on these reads); 32 (16-wide tiles) / 24 (8-wide: rows 8 apart mod 16) separate them
+    static constexpr int HWP = (TW == 16 && !BIG) ? 32 : HW2;
+    static constexpr int HPIP = (TH + 2) * HWP;
     static constexpr int A_ITEMS = (2 * HP + 255) / 256;
-    static constexpr int A_BYTES = HP * 32;
+    static constexpr int A_BYTES = NI * HPIP * 32;
     static constexpr int B_BYTES = 9 * BN * 32;
     static constexpr int B_ITEMS = (9 * BN * 2 + 255) / 256;
     static constexpr int E_BYTES = WM * 32 * BN * 4;
@@ -438,7 +444,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         a_ok[it] = inb;
         a_off0[it] = inb ? (unsigned)((pix_index(gi, gy, gx, p.H, p.W, p.in0_blk) - img_base) * p.in_cs[0] * ESZ + half * 16) : 0u;
         a_off1[it] = inb ? (unsigned)(((long)img * p.H + gy) * p.W + gx) * (unsigned)(p.in_cs[1] * ESZ) + half * 16 : 0u;
-        a_lds[it] = (idx < 2 * C::HP) ? (pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4)) : -1;
+        const int pl = img * C::HPIP + hy * C::HWP + hx;          // LDS slot of the pixel (rows padded to HWP)
+        a_lds[it] = (idx < 2 * C::HP) ? (pl * 32 + ((half ^ ((pl >> 3) & 1)) << 4)) : -1;
     }
     // buffer resources (wave-uniform by construction: kernel arguments and blockIdx only)
     const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -459,11 +466,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     for (int mi = 0; mi < C::MI; ++mi) {
         const int m = wm * C::MI * 32 + mi * 32 + r;
         const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1), img = m >> (C::TWL + C::THL);
-        const int p0 = img * C::HPI + ty * C::HW2 + tx;
+        const int p0 = img * C::HPIP + ty * C::HWP + tx;
 #pragma unroll
         for (int t = 0; t < TAPS0; ++t) {
             const int ky = (TAPS0 == 9) ? t / 3 : 1, kx = (TAPS0 == 9) ? t % 3 : 1;
-            const int pa = p0 + ky * C::HW2 + kx;
+            const int pa = p0 + ky * C::HWP + kx;
             a_rd[mi][t] = pa * 32 + ((h ^ ((pa >> 3) & 1)) << 4);
         }
     }
