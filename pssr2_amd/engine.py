@@ -202,6 +202,7 @@ class Engine:
         if self.reducer is not None:
             self.reducer.finish()
         self._side_join()
+        self.__dict__.get("_keepalive", []).clear()         # temporaries the second stream was reading (RDEngine._bias_grad_job)
         if getattr(self.model, "autograd_grads", False):
             # model.autograd_grads = True: hand the gradients to autograd like any torch.autograd.Function does (copies out of the
             # flat buffer, which the next backward pass overwrites) and leave .grad to it -- what torch.autograd.grad(loss, params),
@@ -284,6 +285,7 @@ class Engine:
         self._side_on = False
         self.__dict__.get("_folds", []).clear()
         self.__dict__.get("_moves", []).clear()
+        self.__dict__.get("_keepalive", []).clear()
 
     def _side_join(self):
         if self._side_on:

@@ -331,6 +331,9 @@ class RDEngine(Engine):
         s64 = self._z64.take(ops.STAT_STRIPES * c, bw.stat_ln)
         if not self._z64.owns(s64):         # first pass: the arena's fallback buffer is reused by the next request, this sum is read later
             s64 = torch.zeros(ops.STAT_STRIPES * c, dtype=torch.float64, device=bw.stat_ln.device)
+            # allocated on the launch stream, used on the second one: kept alive until the streams have joined (a block freed when the
+            # closure dies goes back to the launch stream's pool and can be handed out again while the side kernels still read it)
+            self.__dict__.setdefault("_keepalive", []).append(s64)
         g = self._gbuf(bias)
         grads[id(bias)] = g
 
