@@ -282,3 +282,20 @@ def test_ese_layerscale(ese, dt, c):
         ops.scale_nc(dd, None, gd, None, dt_buf, n, hw, c, code, t_coff=8)
     _close(dgam.cpu(), gam.grad, dt, n * hw)
     _close(_nchw(dt_buf, 0, c), t.grad, dt, 1)
+
+
+def test_dwconv7_pack_batch_equals_single_packs():
+    """pssr_dwconv7_pack_batch (every block's forward and rotated copy by one launch) writes what pssr_dwconv7_pack writes per weight;
+    more items than one launch holds are split."""
+    from pssr2_amd import ops
+    g = torch.Generator().manual_seed(11)
+    ws = [torch.randn(c, 1, 7, 7, generator=g).cuda() for c in (8, 64, 104, 816)] * 13          # 52 items > 48 per launch
+    items, want = [], []
+    for i, w in enumerate(ws):
+        flip = bool(i & 1)
+        items.append((w, torch.empty(49, w.shape[0], device="cuda"), flip))
+        want.append(ops.dwconv7_pack(w, torch.empty(49, w.shape[0], device="cuda"), flip=flip))
+    ops.dwconv7_pack_batch(items)
+    torch.cuda.synchronize()
+    for (w, got, flip), ref in zip(items, want):
+        assert torch.equal(got, ref), (w.shape, flip)
