@@ -151,7 +151,7 @@ int pssr_conv2d_pipeline_mode(int mode);
  * from the environment variables PSSR_<NAME> on first use and changed afterwards only through pssr_set_option(); no launch
  * path reads the environment.  Names: IGEMM_V3 (1: LDS-DMA / counted-wait 3x3 loop for 16-bit layers with > 64 output
  * channels on >= 16x16 images when its 256-pixel tiles fill the chip; 2: whenever the shape allows; 0: the 128-pixel loop), IGEMM_FLAT, IGEMM_BIG, IGEMM_KSPLIT, CONV_EPI8, WGRAD_LEAN,
- * WGRAD_DMA, WGRAD_BLOCKS, WGRAD_BLOCKS_1X1, DWCONV_TILE, DWWG_BLOCKS, LN_BWD_BLOCKS, LN_BWD_PP (and the diagnostic IGEMM_DBG, LN_DBG,
+ * WGRAD_DMA, WGRAD_BLOCKS, WGRAD_BLOCKS_1X1, DWCONV_TILE, DWWG_BLOCKS, LN_BWD_BLOCKS (and the diagnostic IGEMM_DBG, LN_DBG,
  * V3_LDS_PAD: 0 in production).  pssr_set_option returns the previous value (>= 0) or PSSR_ERR_ARG
  * for an unknown name / out-of-range value; pssr_get_option returns the value or PSSR_ERR_ARG. */
 int pssr_set_option(const char* name, int value);

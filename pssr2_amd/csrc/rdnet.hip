@@ -583,7 +583,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(Ref in, const float* __rest
 // workgroup, which share one flush of the statistics (the f64 atomics bound how many workgroups a launch can afford)
 // PP = pixels a wave has in flight per trip (their loads issued together, their reductions independent).  Measured
 // (tools/diag/microbench_ln.py): PP = 2 / 4 change nothing -- what a launch pays besides its bytes is the statistics flush at the end,
-// 2c f64 atomic pairs per workgroup (10-20 us for 256-512 workgroups: PSSR_LN_DBG=1 leaves it out), so the default stays 1
+// 2c f64 atomic pairs per workgroup (10-20 us for 256-512 workgroups: PSSR_LN_DBG=1 leaves it out) -- so only PP = 1 is built
 template <typename T, int NIT, int NT, int PP>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(Ref g, int s2d, int cpad, Ref x, const float* __restrict__ gamma, const float* __restrict__ mean,
                               const float* __restrict__ rstd, MRef dx, int accumulate, long npix, int h, int w, int c, double* stats, int dbg) {
@@ -1095,10 +1095,9 @@ int pssr_layernorm2d_bwd(const void* g, int g_cs, int g_co, int s2d, int c_pad, 
         DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NIT_, NT_, PP_>), dim3((unsigned)blocks), dim3(NT_), 0, (hipStream_t)s, Ref{g, g_cs, g_co}, s2d, \
                                              c_pad, Ref{x, x_cs, x_co}, gamma, mean, rstd, MRef{dx, dx_cs, dx_co}, accumulate, npix, h, w, c, stats, pssr_tunables().ln_dbg)); \
     } while (0)
-    const int pp = pssr_tunables().ln_bwd_pp;
-    if (c <= 256) { if (pp <= 1) PSSR_LN_BWD(1, 1024, 1); else if (pp == 2) PSSR_LN_BWD(1, 1024, 2); else PSSR_LN_BWD(1, 1024, 4); }
-    else if (c <= 512) { if (pp <= 1) PSSR_LN_BWD(2, 1024, 1); else PSSR_LN_BWD(2, 1024, 2); }
-    else if (c <= 1024) { if (pp <= 1) PSSR_LN_BWD(4, 512, 1); else PSSR_LN_BWD(4, 512, 2); }
+    if (c <= 256) PSSR_LN_BWD(1, 1024, 1);
+    else if (c <= 512) PSSR_LN_BWD(2, 1024, 1);
+    else if (c <= 1024) PSSR_LN_BWD(4, 512, 1);
     else PSSR_LN_BWD(8, 256, 1);
 #undef PSSR_LN_BWD
     PSSR_LAUNCH_CHECK();

@@ -21,6 +21,5 @@ struct PssrTunables {
     int dwwg_blocks;        // slabs of the depthwise weight gradient
     int ln_bwd_blocks;      // most workgroups of a LayerNorm2d backward launch (each ends with 2c f64 atomic pairs: 512 -> 256 = -5..-10 us on the 64^2 / 32^2 maps)
     int ln_dbg;             // diagnostic bits of the LayerNorm2d backward kernel (0 in production)
-    int ln_bwd_pp;          // pixels a wave of that kernel keeps in flight (1, 2 or 4 where the registers allow; measured: no gain)
 };
 PssrTunables& pssr_tunables();

@@ -1,4 +1,4 @@
-"""LayerNorm2d forward / backward (csrc/rdnet.hip) at RDNet's shapes, microseconds and algorithmic TB/s.  PSSR_LN_DBG / PSSR_LN_BWD_PP /
+"""LayerNorm2d forward / backward (csrc/rdnet.hip) at RDNet's shapes, microseconds and algorithmic TB/s.  PSSR_LN_DBG /
 PSSR_LN_BWD_BLOCKS select diagnostic variants of the backward kernel."""
 import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import torch
