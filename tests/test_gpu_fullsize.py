@@ -107,7 +107,7 @@ def _train_grads(model, x, loss_of):
 def test_config_c3_training_step_full_size():
     """Config 3 per-GPU shapes (RDResUNet, 128^2 -> 512^2, bf16, batch 32), forward + MS-SSIM/L1 loss + backward: finite, the
     same loss and the same gradients BIT FOR BIT when the step is run twice (order-independent statistic sums, fixed-order partial
-    slabs for the depthwise and dense weight gradients, ticketed fixed-order per-image channel sums), and the loss within 2e-3 of the
+    slabs for the depthwise and dense weight gradients, fixed-order per-image channel sums: one workgroup per image and 32 channels), and the loss within 2e-3 of the
     exact-f32 build on the same weights and tiles."""
     from pssr2_amd.models import RDResUNet
     from pssr2_amd.util import SSIMLoss
