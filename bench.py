@@ -31,18 +31,67 @@ FWD_GFLOP_PER_TILE = 63.30
 PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: f32-input MFMA = vector rate
 PEAK_HBM_GBS = 8000.0
+# layer-wise roofline time per tile, sum over layers of max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) -> the bound on
+# tiles/s per GPU; `layerwise_bound.frac` = measured / bound is the survey's single headline fraction
+LAYERWISE_BOUND = {"c2_train": 10.6e3, "c2_infer": 31.8e3, "c3_train": 6.0e3, "c3_infer": 18.1e3, "c4_train": 2.6e3, "c4_infer": 7.9e3}
 DOMINANT_SYMBOLS = ("conv_igemm_kernelIDF16bLi128ELi0ELi9E", "conv_v3_kernelIDF16bLi128E")   # the 3x3 loops for Cout > 64 (8x16 / 16x16 tiles)
 
 
-class _Done(Exception):
-    """Raised by the timing callback after the last timed step: callback exceptions abort the driver loop (as upstream)."""
+from pssr2_amd.distributed import CooperativeStop  # noqa: E402  (imports torch.distributed only; no HIP call)
 
 
-def whole_pass_roofline(tflops, scope):
+class _Done(CooperativeStop):
+    """Raised by the timing callback after the last timed step: callback exceptions abort the driver loop (as upstream).  Every rank
+    raises it at the same step, so the multi-rank failure watch must not treat it as a rank failure (distributed.CooperativeStop)."""
+
+
+def layerwise(key, tiles_per_s_per_gpu):
+    b = LAYERWISE_BOUND[key]
+    return {"tiles_per_s": b, "frac": round(tiles_per_s_per_gpu / b, 4),
+            "is": "SURVEY.md 8(d): sum over layers of max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) per tile; frac = measured / bound"}
+
+
+def traffic_table(mode):
+    """profiles/traffic.json[mode] (tools/summarize_profile.py from the committed rocprofv3 --pmc passes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[mode]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def kernel_traffic(mode, symbol):
+    """Counter HBM bytes per launch of the kernel whose (mangled) name contains ``symbol``, launch-weighted over its entries."""
+    t = traffic_table(mode)
+    if not t:
+        return None
+    tot_b = tot_n = 0
+    for name, rec in t["kernels"].items():
+        if symbol in name:
+            tot_b += rec["hbm_bytes_per_launch"] * rec.get("launches", 1)
+            tot_n += rec.get("launches", 1)
+    return round(tot_b / tot_n) if tot_n else None
+
+
+def pass_traffic(mode):
+    """Counter HBM bytes of one whole pass (every kernel of a training step / an inference batch) from the same table, or None.  The
+    number of passes the counters saw = the launches of a once-per-pass kernel (AdamW for training, the head's forward for inference)."""
+    t = traffic_table(mode)
+    if not t:
+        return None
+    once = "adamw_kernel" if mode.endswith("train") else "head_fwd_kernel"
+    passes = sum(r.get("launches", 0) for name, r in t["kernels"].items() if once in name)
+    if not passes:
+        return None
+    return round(sum(r["hbm_bytes_per_launch"] * r.get("launches", 1) for r in t["kernels"].values()) / passes)
+
+
+def whole_pass_roofline(tflops, scope, traffic=None):
     """roofline object of an extra leg: the whole pass against the dense MFMA peak (the per-kernel breakdown of the inference pass is
-    profiles/r02_infer_*; its dominant kernels are the training forward's)."""
+    profiles/r04_infer_*; its dominant kernels are the training forward's).  ``traffic``: counter HBM bytes of one pass (one step / one
+    batch) summed over all its kernels, from profiles/traffic.json."""
     return {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_BF16_TFLOPS, 4),
-            "traffic": None, "scope": scope}
+            "traffic": traffic, "traffic_unit": "HBM bytes per pass (one step / one batch), all kernels", "scope": scope}
 
 
 def pmc_traffic(mode):
@@ -152,8 +201,9 @@ class HbmTimer:
         for name, fn in self.orig.items():
             setattr(ops, name, fn)
 
-    def objects(self):
+    def objects(self, mode="train"):
         out = []
+        sym = {"head_conv_fwd": "head_fwd_kernel", "head_conv_bwd_rows": "head_bwd_kernel", "adamw_step_dev": "adamw_kernel", "adamw_step": "adamw_kernel"}
         label = {"head_conv_fwd": "head_fwd_kernel (Reconstruction.conv forward on the pixel-shuffled HR tensor)",
                  "head_conv_bwd_rows": "head_bwd_kernel (its data + weight gradient + bias sums in one pass)",
                  "adamw_step_dev": "adamw_kernel (fused AdamW over the flat parameter buffer)", "adamw_step": "adamw_kernel (fused AdamW over the flat parameter buffer)"}
@@ -165,7 +215,8 @@ class HbmTimer:
             gbs = nb / (ms * 1e-3) / 1e9
             out.append({"kernel": label[name], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 1),
-                        "algorithmic_bytes_per_launch": round(nb / len(ev)), "traffic": None})
+                        "algorithmic_bytes_per_launch": round(nb / len(ev)), "traffic": kernel_traffic(mode, sym[name]),
+                        "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc passes, profiles/traffic.json)"})
         return out
 
 
@@ -220,14 +271,39 @@ def cpu_baseline():
                     ts.append(time.perf_counter() - t0)
         return batch / (sum(ts) / len(ts)), sum(ts)
 
+    def pairgen(n):
+        """Pair generation as the reference's _gen_pair does it for a 512^2 uint8 tile (pssr/data.py:471-495): Pillow BILINEAR 512^2 -> 128^2
+        (the reference's own third-party call; the oracle's numpy restatement of it when Pillow is absent), AdditiveGaussian(13) from numpy's
+        generator, np.round + clip -- one host thread, as one DataLoader worker runs it.  BASELINE.md section 4's pair-generation row."""
+        import numpy as np
+        from oracle import pairs_ref
+        rng = np.random.default_rng(0)
+        tiles = rng.integers(0, 256, size=(8, 512, 512), dtype=np.uint8)
+        try:
+            from PIL import Image
+            reduce_ = lambda a: np.asarray(Image.fromarray(a).resize((128, 128), Image.Resampling.BILINEAR))
+            how = "Pillow BILINEAR"
+        except ImportError:
+            reduce_ = lambda a: pairs_ref.pil_bilinear_u8(a[None], 128, 128)[0]
+            how = "oracle restatement of Pillow BILINEAR (numpy)"
+        t0 = time.perf_counter()
+        for i in range(n):
+            lr = reduce_(tiles[i % 8]).astype(np.float32)
+            lr = pairs_ref.round_clip(pairs_ref.additive_gaussian(lr, rng.normal(0, 13, lr.shape))).astype(np.float32)
+        return n / (time.perf_counter() - t0), how
+
     c1, t1 = train_steps(4, 64, 3)
     c2, t2 = train_steps(4, 128, 3)
     inf, t3 = infer_steps(4, 128, 3)
-    return dict(value=c2, unit="HR tiles/s", cores=threads, kind="port", cpu=cpu_model(),
+    pg, pg_how = pairgen(1500)
+    return dict(pairgen_tiles_per_s=round(pg, 1), pairgen_cores=1,
+                pairgen_sample=f"1500 x (512^2 uint8 -> {pg_how} 128^2 -> + N(0, 13) -> np.round, clip) on ONE host thread "
+                               "(the reference runs it per item inside a DataLoader worker; BASELINE.md section 4 row 'pair generation per tile')",
+                **dict(value=c2, unit="HR tiles/s", cores=threads, kind="port", cpu=cpu_model(),
                 sample=f"CPU oracle, torch fp32, {threads} threads (fastest of 8-128 on this host; {os.cpu_count()} hardware threads present), 1 warm-up + 3 timed steps each: train step (fwd + MS-SSIM/L1 + bwd + AdamW) "
                        f"batch 4 at 128^2->512^2 = value ({t2:.1f} s); c1 shape 64^2->256^2 batch 4: {c1:.2f} tiles/s of 256^2 ({t1:.1f} s); "
                        f"eval forward batch 4 at 128^2->512^2: {inf:.2f} tiles/s ({t3:.1f} s)",
-                c1_train_tiles_per_s=round(c1, 3), c2_infer_tiles_per_s=round(inf, 3))
+                c1_train_tiles_per_s=round(c1, 3), c2_infer_tiles_per_s=round(inf, 3)))
 
 
 def make_tiles(n, res, channels, rank, max_workers=16):
@@ -435,10 +511,55 @@ def main():
         elapsed = time.perf_counter() - t0
         per_step, steps_done = sheet_tiles, args.steps
 
+    # ---- N > 1: the ranks' parameters must be identical after the timed steps (same averaged gradients, same update kernel): a checksum
+    # of the flat parameter buffer (sum and sum of magnitudes, f64) is all-gathered and compared exactly, BEFORE anything rank-specific runs
+    in_sync = None
+    if world > 1 and args.mode == "train":
+        pf = opt._flat[0]["flat"].double()
+        chk = torch.stack([pf.sum(), pf.abs().sum()])
+        every = [torch.zeros_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(every, chk)
+        in_sync = all(torch.equal(every[0], e) for e in every[1:])
+        del pf
+    # ---- N > 1: what the gradient exchange costs and how much of it the backward pass hides
+    res_comm = None
+    if world > 1 and args.mode == "train":
+        flat = model._engine._flat_grad
+        probe = torch.zeros_like(flat)
+        ts = []
+        for i in range(4):
+            barrier()
+            t0 = time.perf_counter()
+            D.sum_flat(probe)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        comm_ms = 1e3 * min(ts[1:])
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, (rank, local, os.uname().nodename))
+        stp = getattr(model._engine, "last_train_stepper", None)
+        exposed = stp.exposed_comm_ms(last=args.steps) if stp is not None else None
+        if rank == 0:
+            res_comm = {"weights_in_sync": in_sync, "weights_in_sync_is": "sum and sum of magnitudes (f64) of the flat parameter buffer after the timed "
+                        "steps, all-gathered and compared exactly over the ranks",
+                        "reduce": "reduce_scatter+all_gather" if D.use_reduce_scatter() else "all_reduce",
+                        "allreduce_bytes_per_step": int(flat.numel() * 4), "comm_ms": round(comm_ms, 3),
+                           "comm_ms_is": "one sum of the whole flat gradient buffer over the ranks (all-reduce, or reduce-scatter + all-gather with "
+                                         "PSSR_DDP_RS=1), nothing else running (min of 3)",
+                           "exposed_ms_per_step": None if exposed is None else round(exposed, 3),
+                           "overlap_frac": None if exposed is None else round(max(0.0, 1.0 - exposed / comm_ms), 3),
+                           "split_graph": bool(stp is not None and stp.graph2 is not None), "ranks_seen": sorted(ranks),
+                           "bus_GBps": round(2 * (world - 1) / world * flat.numel() * 4 / (comm_ms * 1e-3) / 1e9, 1)}
     # ---- roofline of the dominant kernel set: the same kernels once more, one at a time on the launch stream, HIP events
     conv, hbm_objects = None, []
     if rank == 0 and args.dtype in ("bf16", "fp16") and args.mode != "sheet":
         eng = model._engine
+        # (world > 1: only rank 0 runs these two extra optimizer steps -- its weights, optimizer state and BatchNorm buffers are put back
+        # afterwards, so that the ranks leave the bench as they left the timed region: in sync)
+        snap = None
+        if world > 1 and args.mode == "train":
+            st0 = opt._flat[0]
+            snap = ([st0[k].clone() for k in ("flat", "m", "v")] + ([st0["dev"].clone()] if "dev" in st0 else []), st0["step"],
+                    [b.clone() for b in model.buffers()])
         side, eng.side_wgrad = eng.side_wgrad, False
         eng.mark_weights_changed()
         timer.install()
@@ -459,8 +580,18 @@ def main():
         torch.cuda.synchronize()
         timer.remove()
         hbm.remove()
-        hbm_objects = hbm.objects()
+        default_hbm = args.dtype == "bf16" and args.lr_res == 128 and args.channels == 1 and args.batch == (32 if args.mode == "train" else args.batch)
+        hbm_objects = hbm.objects(args.mode if args.model == 'resunet' else f'{args.model}_{args.mode}') if default_hbm else hbm.objects('none')
         eng.side_wgrad = side
+        if snap is not None:
+            st0 = opt._flat[0]
+            for k, t in zip(("flat", "m", "v"), snap[0]):
+                st0[k].copy_(t)
+            if "dev" in st0:
+                st0["dev"].copy_(snap[0][3])
+            st0["step"] = snap[1]
+            for bdst, bsrc in zip(model.buffers(), snap[2]):
+                bdst.copy_(bsrc)
         eng.mark_weights_changed()
         conv = timer.summary()
 
@@ -487,8 +618,14 @@ def main():
                        "driver": {"train": "pssr2_amd.train.train_paired", "infer": "pssr2_amd.predict.predict_images", "sheet": "pssr2_amd.predict.predict_sheet"}[args.mode],
                        "launch": "eager" if args.no_graph or args.mode == "sheet" else "hipGraph replay inside the driver"},
             "step_compute": {"algorithmic_tflops": round(tiles_per_s * gflop_tile * scale / 1e3 / world, 2),
-                             "frac_of_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / peak, 4)},
+                             "frac_of_peak": round(tiles_per_s * gflop_tile * scale / 1e3 / world / peak, 4),
+                             "traffic": pass_traffic(args.mode if args.model == "resunet" else f"{args.model}_{args.mode}")
+                             if (args.dtype == "bf16" and args.lr_res == 128 and args.channels == 1 and args.mode != "sheet") else None,
+                             "traffic_unit": "HBM bytes per step / batch, all kernels (rocprofv3 --pmc passes, profiles/traffic.json)"},
         }
+        lw_key = {("resunet", 1): "c2", ("rdresunet", 1): "c3", ("resunet", 3): "c4"}.get((args.model, args.channels))
+        if lw_key is not None and args.lr_res == (256 if lw_key == "c4" else 128):
+            res["layerwise_bound"] = layerwise(f"{lw_key}_{'train' if args.mode == 'train' else 'infer'}", tiles_per_s / world)
         default_workload = args.dtype == "bf16" and args.lr_res == 128 and args.channels == 1 and args.batch == (32 if args.mode == "train" else args.batch)
         traffic, traffic_src = pmc_traffic(args.mode if args.model == "resunet" else f"{args.model}_{args.mode}") if default_workload else (None, None)
         if conv:
@@ -504,30 +641,8 @@ def main():
         if hbm_objects:
             res["roofline_hbm"] = hbm_objects
 
-    # ---- N > 1: what the gradient exchange costs and how much of it the backward pass hides
-    if world > 1 and args.mode == "train":
-        from pssr2_amd import fastpath
-        flat = model._engine._flat_grad
-        probe = torch.zeros_like(flat)
-        ts = []
-        for i in range(4):
-            barrier()
-            t0 = time.perf_counter()
-            torch.distributed.all_reduce(probe)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        comm_ms = 1e3 * min(ts[1:])
-        ranks = [None] * world
-        torch.distributed.all_gather_object(ranks, (rank, local, os.uname().nodename))
-        stp = getattr(model._engine, "last_train_stepper", None)
-        exposed = stp.exposed_comm_ms(last=args.steps) if stp is not None else None
-        if rank == 0:
-            res["comm"] = {"allreduce_bytes_per_step": int(flat.numel() * 4), "comm_ms": round(comm_ms, 3),
-                           "comm_ms_is": "one all-reduce of the whole flat gradient buffer, nothing else running (min of 3)",
-                           "exposed_ms_per_step": None if exposed is None else round(exposed, 3),
-                           "overlap_frac": None if exposed is None else round(max(0.0, 1.0 - exposed / comm_ms), 3),
-                           "split_graph": bool(stp is not None and stp.graph2 is not None), "ranks_seen": sorted(ranks),
-                           "bus_GBps": round(2 * (world - 1) / world * flat.numel() * 4 / (comm_ms * 1e-3) / 1e9, 1)}
+    if rank == 0 and res_comm is not None:
+        res["comm"] = res_comm
     # ---- extra legs (rank 0 of a 1-GPU run): inference, sheet, exact-f32 training, CPU oracle
     if extras:
         try:
@@ -541,7 +656,9 @@ def main():
                                       f"(the default inference storage of a {args.dtype} model: Engine.storage_dtype)",
                             "algorithmic_tflops": round(len(ids.val_idx) / t * FWD_GFLOP_PER_TILE / 1e3, 2)}
             res["infer"]["roofline"] = whole_pass_roofline(res["infer"]["algorithmic_tflops"], "predict_images pass: every kernel of the forward, "
-                                                           "uint8 clipping included; algorithmic FLOPs of the forward convolutions")
+                                                           "uint8 clipping included; algorithmic FLOPs of the forward convolutions",
+                                                           traffic=pass_traffic("infer"))
+            res["infer"]["layerwise_bound"] = layerwise("c2_infer", res["infer"]["value"])
             del ids
             rng = np.random.default_rng(7)
             sheet = torch.from_numpy(rng.integers(0, 256, size=(1, 4096, 4096), dtype=np.uint8)).to(dev)
@@ -558,6 +675,7 @@ def main():
                             "config": f"predict_sheet: 4096^2 uint8 sheet -> {sheet_tiles} tiles of 128^2 (overlap 32), batch 128, device tiling + "
                                       f"overlap-averaged reassembly, {infer_dt} storage", "dtype": infer_dt, "seconds_per_sheet": round(min(ts[1:]), 4)}
             res["sheet"]["algorithmic_tflops"] = round(sheet_tiles / min(ts[1:]) * FWD_GFLOP_PER_TILE / 1e3, 2)
+            res["sheet"]["layerwise_bound"] = layerwise("c2_infer", res["sheet"]["value"])
             res["sheet"]["roofline"] = whole_pass_roofline(res["sheet"]["algorithmic_tflops"], "predict_sheet: device tiling + forward + "
                                                            "overlap-averaged reassembly, host wall clock; algorithmic FLOPs of the forward convolutions")
             del sheet
@@ -582,7 +700,9 @@ def main():
                                "config": "BASELINE config 3 on one GPU: RDResUNet 1-ch 128^2->512^2, Poisson() device crappifier, MS-SSIM+L1, FusedAdamW, "
                                          "batch 32, train_paired (hipGraph replay), 8 timed steps",
                                "roofline": whole_pass_roofline(round(v_rd * 321.45 / 1e3, 2), "whole training step (pair generation, forward, loss, backward, "
-                                                               "optimizer); algorithmic FLOPs of the convolutions (SURVEY.md 8d: 321.45 GFLOP per tile)")}
+                                                               "optimizer); algorithmic FLOPs of the convolutions (SURVEY.md 8d: 321.45 GFLOP per tile)",
+                                                               traffic=pass_traffic("rdresunet_train")),
+                               "layerwise_bound": layerwise("c3_train", v_rd)}
             del model_rd, ds_rd
             # ---- c4: ResUNet 3-ch multiframe, 256^2 -> 1024^2, MS-SSIM+L1, fp16 storage + dynamic loss scaling, batch 8 per GPU
             torch.manual_seed(0)
@@ -597,7 +717,8 @@ def main():
                                "config": "BASELINE config 4 on one GPU: ResUNet 3-ch (3 frames) 256^2->1024^2, AdditiveGaussian(13), MS-SSIM+L1 over 3 channels, "
                                          "fp16 storage + dynamic loss scaling, FusedAdamW, batch 8, train_paired (hipGraph replay), 5 timed steps",
                                "roofline": whole_pass_roofline(round(v_c4 * 774.65 / 1e3, 2), "whole training step; algorithmic FLOPs of the convolutions "
-                                                               "(SURVEY.md 8d: 774.65 GFLOP per 1024^2 tile)")}
+                                                               "(SURVEY.md 8d: 774.65 GFLOP per 1024^2 tile)", traffic=pass_traffic("c4_train")),
+                               "layerwise_bound": layerwise("c4_train", v_c4)}
             del model_c4, ds_c4
             # ---- the drop-in API fed by a HOST dataset (what a user of the reference passes: Pillow reduction + numpy crappifier on the CPU,
             # DataLoader workers): PCIe-inclusive, never the headline value
@@ -624,6 +745,9 @@ def main():
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if in_sync is False:
+        print("bench: the ranks' parameters differ after the timed steps (comm.weights_in_sync = false)", file=sys.stderr)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -217,7 +217,10 @@ template <typename T, int N> __device__ __forceinline__ void gelu_vec(float* f) 
         gelu_poly_pairs<T, 0, N / 2>(sv, t);
 #pragma unroll
         for (int p = 0; p < N / 2; ++p) {
-            const pssr_v2f g = pk_fma(-u[p], t[p], pssr_v2f{fmaxf(f[2 * p], 0.f), fmaxf(f[2 * p + 1], 0.f)});
+            pssr_v2f g = pk_fma(-u[p], t[p], pssr_v2f{fmaxf(f[2 * p], 0.f), fmaxf(f[2 * p + 1], 0.f)});
+            // min / max return their non-NaN operand: without this a NaN (or an fp16 overflow to inf) in z would come out as a finite
+            // value and never reach the loss or the LossScaler's check.  z * 0 is +-0 for finite z, NaN otherwise (one packed FMA per pair)
+            g = pk_fma(pssr_v2f{f[2 * p], f[2 * p + 1]}, pk_bcast(0.f), g);
             f[2 * p] = g.x; f[2 * p + 1] = g.y;
         }
     }
@@ -238,8 +241,10 @@ template <typename T, int N> __device__ __forceinline__ void gelu_grad_mul_vec(c
         gelu_poly_pairs<T, 1, N / 2>(sv, t);
 #pragma unroll
         for (int p = 0; p < N / 2; ++p) {
-            v[2 * p] *= 0.5f + __builtin_copysignf(t[p].x, z[2 * p]);
-            v[2 * p + 1] *= 0.5f + __builtin_copysignf(t[p].y, z[2 * p + 1]);
+            pssr_v2f d = {0.5f + __builtin_copysignf(t[p].x, z[2 * p]), 0.5f + __builtin_copysignf(t[p].y, z[2 * p + 1])};
+            d = pk_fma(pssr_v2f{z[2 * p], z[2 * p + 1]}, pk_bcast(0.f), d);        // NaN / inf in z propagate (see gelu_vec)
+            v[2 * p] *= d.x;
+            v[2 * p + 1] *= d.y;
         }
     }
 }

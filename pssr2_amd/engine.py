@@ -116,6 +116,8 @@ class _Conv:
 
 
 class Engine:
+    _warned_bf16_infer = False       # the infer_dtype = bfloat16 notice is printed once per process (storage_dtype)
+
     def __init__(self, model):
         self.model = model
         self.plans = {}
@@ -234,6 +236,10 @@ class Engine:
         self._side_on = bool(self.side_wgrad) and self.reducer is None and device.type == "cuda"
         self._pending = {}
         self._deferred = None
+        # queues of a pass that did not reach _finish_backward (an exception mid-backward): their entries must not ride along with this
+        # pass's launches (two writers of one gradient slot in one batched launch; stale temporaries pinned)
+        for q in ("_folds", "_moves", "_keepalive"):
+            self.__dict__.get(q, []).clear()
         if self._side_on and self._side is None:
             self._side = torch.cuda.Stream(device)
 
@@ -372,6 +378,13 @@ class Engine:
             return m.compute_dtype
         inf = getattr(m, "infer_dtype", None)
         if inf is not None:
+            if inf == torch.bfloat16 and not Engine._warned_bf16_infer:
+                Engine._warned_bf16_infer = True
+                import warnings
+                warnings.warn("pssr2_amd: model.infer_dtype = torch.bfloat16 stores inference activations with 8 significant bits; measured "
+                              "against the float32 path that is 0.5-2e-3 dB of PSNR per tile, i.e. AT the 1e-3 dB parity criterion rather than "
+                              "inside it (tests/test_gpu_parity_trained.py).  The default (float16 storage, 1-3e-4 dB) stays inside; keep "
+                              "bfloat16 only for networks whose activations overflow float16.", stacklevel=3)
             return inf
         return torch.float16 if m.compute_dtype == torch.bfloat16 else m.compute_dtype
 

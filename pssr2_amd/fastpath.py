@@ -84,6 +84,16 @@ class _capture:
                 gc.enable()
 
 
+def _all_ranks_ok(ok, device):
+    """True when ``ok`` holds on every rank (MIN all-reduce of a flag; ``device`` None = single process): every rank must take the same
+    path -- replay or launch by launch -- because the collectives of a step are issued from it."""
+    if device is None or not D.is_distributed():
+        return ok
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    return float(flag) >= 1.0
+
+
 class _HostFeed:
     """Static device inputs of a captured graph, refilled from host batches: the host-to-device copy of batch i + 1 runs on its own
     stream into one of two staging buffers while the graph of batch i is still running; a device-to-device copy (~15 us for a c2
@@ -106,11 +116,17 @@ class _HostFeed:
         k = self.k
         self.k ^= 1
         main = torch.cuda.current_stream()
+        if any(t.is_cuda for t in tensors):
+            # a dataset that yields DEVICE tensors (DeviceTileDataset through a DataLoader, a user dataset on the GPU): the batch was made
+            # and collated on the launch stream; the side-stream copy must not read it before it is written
+            self.copy_stream.wait_stream(main)
         with torch.cuda.stream(self.copy_stream):
             if self.free_ev[k] is not None:
                 self.copy_stream.wait_event(self.free_ev[k])           # the previous content of this staging buffer has been consumed
             for dst, src in zip(self.stage[k], tensors):
                 dst.copy_(src, non_blocking=True)
+                if src.is_cuda:
+                    src.record_stream(self.copy_stream)            # its block is not handed out again before this copy has run
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         main.wait_event(ready)
@@ -169,12 +185,14 @@ class TrainStepper:
         self.feed = _HostFeed(device) if host else None
         self.device = torch.device(device)
         self.graph, self.outs, self.eager_done = None, None, 0
+        self.eager_only = False        # set when the step could not be captured (see step): ordinary launches from then on
         self._reduced = False
         # data-parallel: the step is captured as TWO graphs split where the gradients of the reconstruction head, the decoder and
         # the deepest encoder block (the tail of the engine's flat buffer, ~85 % of a ResUNet's bytes) are final; their all-reduce is
         # launched between the two replays and runs on RCCL's stream under the rest of the backward pass (PSSR_OVERLAP=0: one graph,
         # one all-reduce after it)
-        self.split = self.world > 1 and os.environ.get("PSSR_OVERLAP", "1") != "0"
+        # PSSR_DDP_SPLIT=0 (older name: PSSR_OVERLAP=0) is the fallback should the two-graph schedule misbehave on a real RCCL node
+        self.split = self.world > 1 and os.environ.get("PSSR_DDP_SPLIT", os.environ.get("PSSR_OVERLAP", "1")) != "0"
         self.graph2, self.split_at = None, 0
         self.comm_events = [] if os.environ.get("PSSR_COMM_STATS") == "1" else None     # (after graph 2, after the all-reduces) per step
         self.engine.last_train_stepper = self       # the stepper of the model's most recent train_paired call (bench.py / tests read its statistics)
@@ -217,7 +235,7 @@ class TrainStepper:
         if self.in_graph_optim:
             return
         if self.world > 1 and not self._reduced:
-            torch.distributed.all_reduce(eng._flat_grad)
+            D.sum_flat(eng._flat_grad)
         self._reduced = False
         eng.publish_grads()             # a replayed backward wrote the flat buffer but ran no Python
         if self.scaler is not None:
@@ -264,7 +282,7 @@ class TrainStepper:
             self._after()                                   # below then contains the packed-weight refresh)
             self.eager_done += 1
             return out
-        if self.graph is None:
+        if self.graph is None and not self.eager_only:
             torch.cuda.synchronize()
             if self.split:
                 err = None
@@ -284,15 +302,29 @@ class TrainStepper:
                     torch.cuda.synchronize()
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
-                with _capture(g):
-                    self.outs = self._body()
-                self.graph = g
+                err = None
+                try:
+                    with _capture(g):
+                        self.outs = self._body()
+                except Exception as e:
+                    # a loss_fn that synchronises with the host (.item(), data-dependent Python control flow) or an op that cannot be
+                    # captured: the reference accepts any nn.Module loss (pssr/train.py:19), so run this stepper launch by launch
+                    err = e
+                if _all_ranks_ok(err is None, self.engine._flat_grad.device if self.world > 1 else None):
+                    self.graph = g
+                else:
+                    self._capture_failed(err)
+        if self.eager_only:
+            out = self._body()
+            self._after()
+            self._leave_graph()
+            return out
         if self.graph2 is not None:
             flat, a0 = self.engine._flat_grad, self.split_at
             self.graph.replay()
-            h1 = torch.distributed.all_reduce(flat[a0:], async_op=True)      # waits for graph 1 on RCCL's stream, runs under graph 2
+            h1 = D.sum_flat(flat[a0:], async_op=True)       # waits for graph 1 on RCCL's stream, runs under graph 2
             self.graph2.replay()
-            h2 = torch.distributed.all_reduce(flat[:a0], async_op=True)
+            h2 = D.sum_flat(flat[:a0], async_op=True)
             if self.comm_events is not None:
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ea.record()
@@ -354,6 +386,20 @@ class TrainStepper:
         self.graph, self.graph2, self.split_at = g1, g2, eng.grad_split_offset()
         self.outs = (hr, lr, hr_hat.detach(), loss.detach())
 
+    def _capture_failed(self, err):
+        """The step cannot be replayed: forget the aborted capture and keep going launch by launch (what PSSR_HOST_GRAPH=0 /
+        PSSR_GRAPH=0 select up front).  The batch whose capture failed is then run eagerly by ``step``."""
+        why = f"{type(err).__name__}: {err}" if err is not None else "another rank could not capture it"
+        if self.rank == 0 or err is not None:
+            print(f"[pssr2_amd] rank {self.rank}: the training step could not be captured into a hipGraph ({why}); "
+                  "running it launch by launch (PSSR_GRAPH=0 selects this from the start)", flush=True)
+        self.graph = self.graph2 = None
+        self.split, self.eager_only = False, True
+        self.engine.reset_backward_state()
+        for p in self.model.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+
     def exposed_comm_ms(self, last=None):
         """Mean time per step the launch stream sat waiting for the gradient all-reduces after the backward graph had finished
         (PSSR_COMM_STATS=1): the part of the communication that the backward pass did not hide."""
@@ -385,6 +431,7 @@ class EvalStepper:
         self.cur = _Cursor(dataset, batch_size, max(len(dataset), len(dataset.val_idx), batch_size), device) if not host else None
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.graph, self.outs, self.eager_done = None, None, 0
+        self.eager_only = False
         self.sig = None
 
     def _signature(self):
@@ -451,7 +498,7 @@ class EvalStepper:
                 return out
             self.pos += self.batch
             self.count += 1
-        if self.eager_done < 1:
+        if self.eager_done < 1 or (self.eager_only and self.graph is None):
             self.eager_done += 1
             out = self._run(None)
             self.sig = self._signature()
@@ -461,9 +508,19 @@ class EvalStepper:
             if self.weights_move:
                 self.engine.mark_weights_changed()          # capture the packed-weight refresh and the BatchNorm folds too
             g = torch.cuda.CUDAGraph()
-            with _capture(g):
-                self.outs = self._run(None)
-            self.graph = g
+            try:
+                with _capture(g):
+                    self.outs = self._run(None)
+                self.graph = g
+            except Exception as e:          # e.g. a loss_fn that synchronises with the host: ordinary launches for this stepper
+                print(f"[pssr2_amd] the evaluation pass could not be captured into a hipGraph ({type(e).__name__}: {e}); "
+                      "running it launch by launch", flush=True)
+                self.eager_only = True
+                torch.cuda.synchronize()
+        if self.eager_only:
+            if self.weights_move:
+                self.engine.mark_weights_changed()
+            return self._run(None)
         self.graph.replay()
         return self.outs
 

@@ -105,3 +105,22 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64 and d["scaling"] == "weak"
     assert sorted(x[0] for x in d["comm"]["ranks_seen"]) == [0, 1] and d["comm"]["split_graph"] is True
     assert d["value"] > 0 and d["steps"] == 4
+    # the line says whether the ranks' parameters were identical after the timed steps (a false exits non-zero)
+    assert d["comm"]["weights_in_sync"] is True and d["comm"]["reduce"] == "all_reduce"
+    assert "roofline" in d            # rank 0's instrumented pass still runs (after the probe; its weights are put back afterwards)
+
+
+def test_bench_gpus_2_reduce_scatter_knob():
+    """PSSR_DDP_RS=1: the gradient sum as reduce-scatter + all-gather of the flat buffer, through the same two-graph
+    schedule; the ranks stay in sync.  PSSR_DDP_SPLIT=0 (the fallback knob, item 4c) in the same run: one graph, one sum after it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PSSR_BENCH_FORCE_DEVICE="0", PSSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PSSR_DDP_RS="1")
+    for split in ("1", "0"):
+        env["PSSR_DDP_SPLIT"] = split
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--tiles", "256",
+                            "--no-cpu-baseline", "--no-extras", "--tile-workers", "4"], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+        assert d["comm"]["weights_in_sync"] is True and d["comm"]["reduce"] == "reduce_scatter+all_gather"
+        assert d["comm"]["split_graph"] is (split == "1")

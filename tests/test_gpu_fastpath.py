@@ -274,3 +274,68 @@ def test_predict_images_host_dataset_graph_equals_eager():
         for k in ref:
             assert got[k].dtype == np.uint8 and np.array_equal(got[k], ref[k]) and np.array_equal(again[k], ref[k]), k
     assert any(key[-1] == "host" for key in model._engine._eval_steppers)
+
+
+def test_host_feed_waits_for_device_made_batches():
+    """a dataset that yields DEVICE tensors through a DataLoader (DeviceTileDataset with dataloader_kwargs) takes the host-fed
+    replay too; its batches are made and collated on the launch stream, so the copy stream has to wait for them: predictions equal the
+    launch-by-launch loop's bit for bit, over several batches."""
+    from pssr2_amd import fastpath as FP
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.predict import predict_images
+    torch.manual_seed(6)
+    model = ResUNet(hidden=[16, 32], depth=1).cuda()
+    model.compute_dtype = torch.bfloat16
+    ds = DeviceTileDataset(_tiles(37, 64, seed=3), hr_res=64, lr_scale=4, crappifier=None, val_split=1.0, rotation=False, device="cuda")
+    kw = dict(num_workers=0)
+    assert FP.supports_host(model, ds, "cuda")
+    os.environ["PSSR_HOST_GRAPH"] = "0"
+    try:
+        ref = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None, dataloader_kwargs=kw)
+    finally:
+        os.environ.pop("PSSR_HOST_GRAPH", None)
+    for _ in range(2):
+        got = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None, dataloader_kwargs=kw)
+        assert list(got) == list(ref) and len(ref) == 37
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), k
+    assert any(key[-1] == "host" for key in model._engine._eval_steppers)
+
+
+class _SyncingLoss(torch.nn.Module):
+    """A loss the reference accepts (any nn.Module, pssr/train.py:19) that cannot be captured: it reads a value back to the host."""
+
+    def forward(self, a, b):
+        d = (a - b).abs().mean()
+        return d * (2.0 if float(d.detach()) > 1e9 else 1.0)
+
+
+def test_uncapturable_loss_falls_back_to_eager_launches(capsys):
+    """a capture error must not abort train_paired: the stepper prints one warning and goes on launch by launch, with the
+    results of the eager loop (PSSR_GRAPH=0)."""
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import ArrayDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+
+    def run(graph):
+        os.environ["PSSR_GRAPH"] = "1" if graph else "0"
+        try:
+            torch.manual_seed(3)
+            random.seed(11)
+            np.random.seed(5)
+            model = ResUNet(hidden=[16, 32], depth=1).cuda()
+            model.compute_dtype = torch.float32
+            ds = ArrayDataset(_tiles(44, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.2, rotation=True)
+            tl, vl = train_paired(model, ds, 8, _SyncingLoss(), FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3), 2, device="cuda", log_frequency=1)
+            return tl, vl, getattr(model._engine, "last_train_stepper", None)
+        finally:
+            os.environ.pop("PSSR_GRAPH", None)
+    tl, vl, stp = run(True)
+    msg = capsys.readouterr().out
+    assert stp is not None and stp.eager_only and stp.graph is None and "could not be captured" in msg
+    tl0, vl0, _ = run(False)
+    np.testing.assert_allclose(tl, tl0, rtol=2e-5)
+    np.testing.assert_allclose(vl, vl0, rtol=2e-5)

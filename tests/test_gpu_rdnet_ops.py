@@ -235,6 +235,35 @@ def test_gelu_fused_1x1(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_gelu_propagates_nonfinite(dt):
+    """A NaN / inf in z must reach the consumers of gelu(z) and gelu'(z) (the polynomial GELU of the 16-bit builds is built from min / max,
+    which return their non-NaN operand): the output pixel of the fused 1x1 conv and the input gradient at that element are non-finite,
+    every other pixel stays finite."""
+    from pssr2_amd import ops, _lib as L
+    n, ci, co, h, w = 1, 32, 16, 4, 8
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, ci, h, w, generator=g)
+    z[0, 5, 1, 2] = float("nan")
+    z[0, 7, 2, 3] = float("inf")
+    wt = torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5
+    zd = _nhwc(z, ci, dt)
+    out = torch.zeros(n, h, w, co, dtype=dt, device="cuda")
+    ops.conv2d(zd, ci, ops.pack_conv_weight(wt.cuda().contiguous(), code, mode=0), out, co, n=n, h=h, w=w, gelu_in=True)
+    fin = torch.isfinite(out.float()).all(-1)[0].cpu()
+    bad = torch.zeros(h, w, dtype=torch.bool)
+    bad[1, 2] = bad[2, 3] = True
+    assert torch.equal(~fin, bad), fin
+    dy = _nhwc(torch.randn(n, co, h, w, generator=g), co, dt)
+    dz = torch.zeros(n, h, w, ci, dtype=dt, device="cuda")
+    ops.conv2d(dy, co, ops.pack_conv_weight(wt.cuda().contiguous(), code, mode=1), dz, ci, n=n, h=h, w=w, epilogue=L.EPI_DGRAD_GELU, aux=zd)
+    dzf = torch.isfinite(dz.float())[0].cpu()
+    assert not dzf[1, 2, 5] and not dzf[2, 3, 7]
+    dzf[1, 2, 5] = dzf[2, 3, 7] = True
+    assert dzf.all()
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("ese", [True, False])
 @pytest.mark.parametrize("c", [24, 328])
 def test_ese_layerscale(ese, dt, c):
