@@ -252,6 +252,22 @@ int pssr_relu_bwd_stats(const void* dout, int do_cs, int do_co, const void* out,
                         void* dz, int dz_cs, int dz_co, double* stats, int64_t npix, int c, int dtype,
                         pssr_stream_t stream);
 
+/* The same with the gradient of the block output formed in the loader instead of read from a tensor (16-bit storage, c a power of two;
+ * PSSR_ERR_UNSUPPORTED otherwise -- the caller then runs the separate kernels):
+ *   _pool:      d(out) = dskip + route(dpool): the block output feeds F.max_pool2d(x, 2) (resunet.py:76, first maximum in row-major
+ *               window order takes the gradient, as torch) and the decoder's skip connection (resunet.py:84); h, w even
+ *   _unshuffle: d(out)[n, y, x, 4 ch + 2 i + j] = dhi[n, 2 y + i, 2 x + j, ch]: the block output went through F.pixel_shuffle(x, 2)
+ *               (resunet.py:82) into the first c / 4 channels of the next level's concat buffer; c >= 32
+ * dz is bit for bit what pssr_maxpool2_bwd / pssr_pixel_shuffle(inverse) followed by pssr_relu_bwd_stats write. */
+int pssr_relu_bwd_stats_pool(const void* dpool, int dp_cs, int dp_co, const void* dskip, int ds_cs, int ds_co,
+                             const void* out, int o_cs, int o_co, const void* y, int y_cs, int y_co,
+                             const float* mean, const float* invstd, void* dz, int dz_cs, int dz_co, double* stats,
+                             int n, int h, int w, int c, int dtype, pssr_stream_t stream);
+int pssr_relu_bwd_stats_unshuffle(const void* dhi, int dh_cs, int dh_co, const void* out, int o_cs, int o_co,
+                                  const void* y, int y_cs, int y_co, const float* mean, const float* invstd,
+                                  void* dz, int dz_cs, int dz_co, double* stats, int n, int h, int w, int c, int dtype,
+                                  pssr_stream_t stream);
+
 /* out[row][c] += sum over pixels (bias gradients); out is a statistic buffer of PSSR_STAT_ROWS x c doubles */
 int pssr_channel_sum_nhwc(const void* x, int cs, int co, int64_t npix, int c, double* out, int dtype,
                           pssr_stream_t stream);

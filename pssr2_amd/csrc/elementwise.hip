@@ -512,6 +512,153 @@ __global__ __launch_bounds__(TPB) void relu_bwd_stats8_kernel(Ref dout, Ref out,
     }
 }
 
+// Combine the 8-channel partial sums s1 / s2 that the threads of a workgroup hold for their fixed channel group (threads tid, tid + cg,
+// ... share channels; TPB is a multiple of cg) and add them to the striped f64 statistic rows: [sum][C] | [sum * xhat][C].
+__device__ __forceinline__ void flush_stats8(const float (&s1)[8], const float (&s2)[8], int cg, int c, double* __restrict__ stats, float* lds) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lds[tid * 16 + e] = s1[e]; lds[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    double* dst = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+    for (int j = tid; j < cg * 16; j += TPB) {
+        const int g_ = j >> 4, q = j & 15;
+        float t = 0.f;
+        for (int k = g_; k < TPB; k += cg) t += lds[k * 16 + q];
+        stat_add(dst + (long)(q >> 3) * c + g_ * 8 + (q & 7), (long)PSSR_STAT_STRIPES * 2 * c, t);
+    }
+    __syncthreads();
+}
+
+// relu_bwd_stats8 with the max-pool backward folded into its loader (round 4: 4 launches and 3 tensor passes per encoder level less on the
+// backward's dependent chain).  The block output `out` feeds max_pool2d AND the decoder's skip, so
+//   d(out) = dskip + route(dpool)   (the FIRST maximum of a 2x2 window in row-major order takes the pooled gradient: torch semantics)
+// is formed per window in registers -- rounded to the storage type exactly where maxpool2_bwd_kernel used to store it, so dz is bit for
+// bit what the two kernels produced -- then masked by out > 0 and summed into the BatchNorm-backward statistics.  An item is one 2x2
+// window x 8 channels: out / dskip / y are read once (4 x 16 bytes each), dpool once, dz is written once.  H and W even.
+template <typename T>
+__global__ __launch_bounds__(TPB) void relu_bwd_stats8_pool_kernel(Ref dpool, Ref dskip, Ref out, Ref y, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, MRef dz, double* __restrict__ stats,
+                                                                   int n, int h, int w, int c, int cg_log2) {
+    using X = TT<T>;
+    __shared__ float lds[TPB * 16];
+    const int cg = 1 << cg_log2;
+    const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c0 = (int)(t0 & (cg - 1)) * 8;
+    float mu[8], is[8], s1[8], s2[8];
+    load4(mean + c0, mu); load4(mean + c0 + 4, mu + 4); load4(invstd + c0, is); load4(invstd + c0 + 4, is + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const int ho = h >> 1, wo = w >> 1;
+    const long total = ((long)n * ho * wo) << cg_log2;
+    for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+        long win = i >> cg_log2;
+        const int ox = (int)(win % wo); win /= wo;
+        const int oy = (int)(win % ho);
+        const long img = win / ho;
+        const long p00 = (img * h + 2 * oy) * w + 2 * ox;
+        const long pp[4] = {p00, p00 + 1, p00 + w, p00 + w + 1};
+        float ov[4][8], gv[4][8], yv[4][8], gp[8];
+        X::unpack(*(const u32x4*)at<T>(dpool, (img * ho + oy) * wo + ox, c0), gp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            X::unpack(*(const u32x4*)at<T>(out, pp[k], c0), ov[k]);
+            X::unpack(*(const u32x4*)at<T>(dskip, pp[k], c0), gv[k]);
+            X::unpack(*(const u32x4*)at<T>(y, pp[k], c0), yv[k]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int best = 0; float bv = ov[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (ov[k][e] > bv) { bv = ov[k][e]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == best) gv[k][e] += gp[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r[8];
+            X::unpack(X::pack(gv[k]), r);            // d(out) in the storage type, as the separate max-pool backward stored it
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                r[e] = ov[k][e] > 0.f ? r[e] : 0.f;
+                s1[e] += r[e];
+                s2[e] += r[e] * (yv[k][e] - mu[e]) * is[e];
+            }
+            *(u32x4*)at<T>(dz, pp[k], c0) = X::pack(r);
+        }
+    }
+    flush_stats8(s1, s2, cg, c, stats, lds);
+}
+
+// relu_bwd_stats8 with the inverse pixel shuffle (r = 2) folded into its loader: the block output was shuffled into the first c / 4
+// channels of the next decoder level's concat buffer, so d(out)[n, y, x, 4 ch + 2 i + j] = dcat[n, 2 y + i, 2 x + j, ch].  An item is one
+// low-resolution pixel x 32 channels = 8 channels (16 bytes) of each of its 4 high-resolution pixels, de-interleaved in registers as
+// pixel_shuffle2_kernel does; four 8-channel pieces of out / y / dz per item.  c a power of two >= 32.
+template <typename T>
+__global__ __launch_bounds__(TPB) void relu_bwd_stats8_unshuffle_kernel(Ref dhi, Ref out, Ref y, const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd, MRef dz, double* __restrict__ stats,
+                                                                        int n, int h, int w, int c, int cg_log2) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    __shared__ float lds[TPB * 16];
+    const int cg = 1 << cg_log2;                        // 32-channel groups
+    const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int g32 = (int)(t0 & (cg - 1)), c0 = g32 * 32;
+    float s1[4][8], s2[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[q][e] = 0.f; s2[q][e] = 0.f; }
+    const long total = ((long)n * h * w) << cg_log2;
+    for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+        long pix = i >> cg_log2;
+        const int x = (int)(pix % w); pix /= w;
+        const int yy = (int)(pix % h);
+        const long img = pix / h;
+        const long plo = (img * h + yy) * w + x;
+        unsigned short e16[32];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long phi = (img * 2 * h + 2 * yy + (k >> 1)) * (2L * w) + 2 * x + (k & 1);
+            unsigned short v[8];
+            *(u32x4*)v = *(const u32x4*)((const unsigned short*)dhi.p + phi * dhi.cs + dhi.co + g32 * 8);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) e16[4 * ch + k] = v[ch];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gv[8], ov[8], yv[8], mu[8], is[8];
+            X::unpack(*(const u32x4*)(e16 + 8 * q), gv);
+            X::unpack(*(const u32x4*)at<T>(out, plo, c0 + 8 * q), ov);
+            X::unpack(*(const u32x4*)at<T>(y, plo, c0 + 8 * q), yv);
+            load4(mean + c0 + 8 * q, mu); load4(mean + c0 + 8 * q + 4, mu + 4);
+            load4(invstd + c0 + 8 * q, is); load4(invstd + c0 + 8 * q + 4, is + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gv[e] = ov[e] > 0.f ? gv[e] : 0.f;
+                s1[q][e] += gv[e];
+                s2[q][e] += gv[e] * (yv[e] - mu[e]) * is[e];
+            }
+            *(u32x4*)at<T>(dz, plo, c0 + 8 * q) = X::pack(gv);
+        }
+    }
+    // four rounds through the 16 KB combine buffer: round q carries channels c0 + 8 q .. + 7 of every 32-channel group
+    const int tid = threadIdx.x;
+    double* dst = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lds[tid * 16 + e] = s1[q][e]; lds[tid * 16 + 8 + e] = s2[q][e]; }
+        __syncthreads();
+        for (int j = tid; j < cg * 16; j += TPB) {
+            const int g_ = j >> 4, r = j & 15;
+            float t = 0.f;
+            for (int k = g_; k < TPB; k += cg) t += lds[k * 16 + r];
+            stat_add(dst + (long)(r >> 3) * c + g_ * 32 + 8 * q + (r & 7), (long)PSSR_STAT_STRIPES * 2 * c, t);
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ void channel_sum_kernel(Ref x, double* out, long npix, int c, ChanMap m) {
     __shared__ float lds[TPB * 4];
@@ -698,6 +845,54 @@ int pssr_pixel_shuffle(const void* lo, int lo_cs, int lo_co, void* hi, int hi_cs
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL(pixel_shuffle_kernel<T>, dim3(grid1d(total)), dim3(TPB), 0, (hipStream_t)s, Ref{lo, lo_cs, lo_co},
                                          MRef{hi, hi_cs, hi_co}, n, h, w, c_hi, r, inverse));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_relu_bwd_stats_pool(const void* dpool, int dp_cs, int dp_co, const void* dskip, int ds_cs, int ds_co, const void* out, int o_cs, int o_co,
+                             const void* y, int y_cs, int y_co, const float* mean, const float* invstd, void* dz, int dz_cs, int dz_co,
+                             double* stats, int n, int h, int w, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dpool && dskip && out && y && mean && invstd && dz && stats && n > 0 && h > 1 && w > 1 && c > 0, PSSR_ERR_ARG, "relu_bwd_stats_pool: bad args");
+    PSSR_CHECK(dtype == PSSR_BF16 || dtype == PSSR_F16, PSSR_ERR_UNSUPPORTED, "relu_bwd_stats_pool: 16-bit storage only (dtype %d)", dtype);
+    PSSR_CHECK(h % 2 == 0 && w % 2 == 0, PSSR_ERR_UNSUPPORTED, "relu_bwd_stats_pool: %dx%d is not even", h, w);
+    PSSR_CHECK(c >= 8 && c <= 8 * TPB && (c & (c - 1)) == 0, PSSR_ERR_UNSUPPORTED, "relu_bwd_stats_pool: c=%d must be a power of two in [8, %d]", c, 8 * TPB);
+    PSSR_CHECK(((dp_cs | dp_co | ds_cs | ds_co | o_cs | o_co | y_cs | y_co | dz_cs | dz_co) & 7) == 0, PSSR_ERR_ARG, "relu_bwd_stats_pool: strides / offsets must be multiples of 8");
+    CHECK_REF("relu_bwd_stats_pool dpool", dp_cs, dp_co, c); CHECK_REF("relu_bwd_stats_pool dskip", ds_cs, ds_co, c);
+    CHECK_REF("relu_bwd_stats_pool out", o_cs, o_co, c); CHECK_REF("relu_bwd_stats_pool y", y_cs, y_co, c); CHECK_REF("relu_bwd_stats_pool dz", dz_cs, dz_co, c);
+    int lg = 0;
+    while ((8 << lg) < c) ++lg;
+    const long threads = ((long)n * (h / 2) * (w / 2)) << lg;
+    const int grid = (int)((threads + TPB - 1) / TPB < 2048 ? (threads + TPB - 1) / TPB : 2048);
+    if (dtype == PSSR_BF16)
+        hipLaunchKernelGGL(relu_bwd_stats8_pool_kernel<bf16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dpool, dp_cs, dp_co}, Ref{dskip, ds_cs, ds_co},
+                           Ref{out, o_cs, o_co}, Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, n, h, w, c, lg);
+    else
+        hipLaunchKernelGGL(relu_bwd_stats8_pool_kernel<f16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dpool, dp_cs, dp_co}, Ref{dskip, ds_cs, ds_co},
+                           Ref{out, o_cs, o_co}, Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, n, h, w, c, lg);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_relu_bwd_stats_unshuffle(const void* dhi, int dh_cs, int dh_co, const void* out, int o_cs, int o_co, const void* y, int y_cs, int y_co,
+                                  const float* mean, const float* invstd, void* dz, int dz_cs, int dz_co, double* stats,
+                                  int n, int h, int w, int c, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(dhi && out && y && mean && invstd && dz && stats && n > 0 && h > 0 && w > 0 && c > 0, PSSR_ERR_ARG, "relu_bwd_stats_unshuffle: bad args");
+    PSSR_CHECK(dtype == PSSR_BF16 || dtype == PSSR_F16, PSSR_ERR_UNSUPPORTED, "relu_bwd_stats_unshuffle: 16-bit storage only (dtype %d)", dtype);
+    PSSR_CHECK(c >= 32 && c <= 32 * TPB && (c & (c - 1)) == 0, PSSR_ERR_UNSUPPORTED, "relu_bwd_stats_unshuffle: c=%d must be a power of two in [32, %d]", c, 32 * TPB);
+    PSSR_CHECK(((dh_cs | dh_co | o_cs | o_co | y_cs | y_co | dz_cs | dz_co) & 7) == 0, PSSR_ERR_ARG, "relu_bwd_stats_unshuffle: strides / offsets must be multiples of 8");
+    PSSR_CHECK(dh_co + c / 4 <= dh_cs, PSSR_ERR_ARG, "relu_bwd_stats_unshuffle: high-resolution slice exceeds its stride");
+    CHECK_REF("relu_bwd_stats_unshuffle out", o_cs, o_co, c); CHECK_REF("relu_bwd_stats_unshuffle y", y_cs, y_co, c);
+    CHECK_REF("relu_bwd_stats_unshuffle dz", dz_cs, dz_co, c);
+    int lg = 0;
+    while ((32 << lg) < c) ++lg;
+    const long threads = ((long)n * h * w) << lg;
+    const int grid = (int)((threads + TPB - 1) / TPB < 2048 ? (threads + TPB - 1) / TPB : 2048);
+    if (dtype == PSSR_BF16)
+        hipLaunchKernelGGL(relu_bwd_stats8_unshuffle_kernel<bf16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dhi, dh_cs, dh_co}, Ref{out, o_cs, o_co},
+                           Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, n, h, w, c, lg);
+    else
+        hipLaunchKernelGGL(relu_bwd_stats8_unshuffle_kernel<f16_t>, dim3(grid), dim3(TPB), 0, (hipStream_t)s, Ref{dhi, dh_cs, dh_co}, Ref{out, o_cs, o_co},
+                           Ref{y, y_cs, y_co}, mean, invstd, MRef{dz, dz_cs, dz_co}, stats, n, h, w, c, lg);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

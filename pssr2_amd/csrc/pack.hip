@@ -206,7 +206,12 @@ __global__ __launch_bounds__(256) void unpack9_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int PL = 1 << pl, ppb = 1024 >> pl;            // part lanes, pairs per workgroup-iteration
     const int pos = tid & ((256 >> pl) - 1), plane = tid >> (8 - pl);
-    for (long base = (long)blockIdx.x * ppb; base < total_nk; base += (long)gridDim.x * ppb) {
+    // workgroups are dealt round-robin to the 8 XCDs, and with many part lanes a workgroup reads only 16 * (256 >> pl) bytes of every
+    // 128-byte line of the partial slabs: neighbours in `base` share lines, so they are numbered onto ONE XCD (its L2 then serves the
+    // second reader; with the plain numbering every line came from HBM twice: 65 MB fetched per 37.7 MB of slabs, profiles/traffic.json)
+    const unsigned G = gridDim.x;
+    const unsigned bid = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    for (long base = (long)bid * ppb; base < total_nk; base += (long)gridDim.x * ppb) {
         const long i = base + pos * 4;
         float4 v[TAPS];
 #pragma unroll

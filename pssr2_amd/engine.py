@@ -35,6 +35,13 @@ _COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
 _ABLATE_XCOL = __import__("os").environ.get("PSSR_ABLATE_XCOL", "0") == "1"      # timing ablation (wrong gradients): skip the two passes over d(pre) that serve the input channel
 _XCOL_SIDE = __import__("os").environ.get("PSSR_XCOL_SIDE", "0") == "1"
 _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
+# PSSR_ABLATE=<comma list> (timing ablations for tools/diag/ab_env.sh: WRONG gradients on purpose, never set in a product run): leave single
+# launches of the step out to price what folding them into a neighbour could buy at most -- xdgrad / xwgrad (the two passes over d(pre) that
+# serve the input channel), poolbwd (maxpool2_bwd), unshuf (inverse pixel shuffle), shuf (forward pixel shuffle), pool (forward max pool),
+# apply (bn_bwd_apply), relustats (relu_bwd_stats), unpack (partial-slab reduction of the weight gradients), gzero (flat gradient memset)
+_FUSE_DOUT = __import__("os").environ.get("PSSR_FUSE_DOUT", "1") != "0"
+_OVERWRITE_GRADS = __import__("os").environ.get("PSSR_OVERWRITE_GRADS", "1") != "0"
+_ABL = frozenset(x for x in __import__("os").environ.get("PSSR_ABLATE", "").split(",") if x)
 
 class _Arena:
     """Bump allocator for the many small per-channel vectors (one memset zeroes all statistics)."""
@@ -185,7 +192,12 @@ class Engine:
         for prm, view in zip(self.model.parameters(), self._gviews):
             if prm.grad is not None and prm.grad.data_ptr() == view.data_ptr():
                 prm.grad = prm.grad.clone()
-        self._flat_grad.zero_()
+        # the ~240 MB memset of the flat buffer (32 us at the head of every backward pass) is only needed where a slot is ACCUMULATED into:
+        # a plain ResUNet overwrites every weight-gradient slot (one unpack per weight; Reconstruction.pre's two sources write disjoint
+        # channel ranges), BatchNorm / bias gradients are stored or copied, and the slots nothing writes -- biases of convolutions in front of
+        # a batch-statistics BatchNorm, whose gradient is exactly zero -- keep the zeros of the allocation (_overwrite_grads)
+        if not getattr(self, "_overwrite_grads", False) and "gzero" not in _ABL:
+            self._flat_grad.zero_()
         if self.reducer is not None:
             self.reducer.begin()
         self._side_begin(device)
@@ -708,7 +720,7 @@ class Engine:
             else:
                 dst, off = blk.out, 0
             self._block_forward(p, blk, m.encoder[i], src, cin, i == 0, dst, off, train)
-            if i < Lv - 1:
+            if i < Lv - 1 and "pool" not in _ABL:
                 ops.maxpool2(dst, p.pooled[i], n, *p.dims[i], hid[i], code, in_coff=off)
         deep = p.enc[Lv - 1].out
         if p.epool is not None:         # pssr/models/resunet.py:78-79
@@ -718,7 +730,8 @@ class Engine:
         # decoder
         for l in range(Lv - 2, -1, -1):
             prev = deep if l == Lv - 2 else p.dec[l + 1].out
-            ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
+            if "shuf" not in _ABL:
+                ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
             blk = p.dec[l]
             self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train)
         feat = p.dec[0].out if Lv > 1 else deep
@@ -766,25 +779,29 @@ class Engine:
         dpre_hr = bw.dpre.view(n, H, W, h0)
         if ops.head_conv_supported(code, h0, self.cout):
             # final conv straight from the f32 NCHW gradient ("x*128+128" folded into g_scale)
-            bw.sum64.zero_()
-            ops.channel_stats_nchw(dout, bw.sum64, 128.0, 0.0)
-            gb = torch.empty(2 * self.cout, dtype=torch.float32, device=dev)
-            ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * 2 * self.cout], gb)
-            grads[id(rec.conv.bias)] = gb[:self.cout]
             gw = grads[id(rec.conv.weight)] = self._gbuf(rec.conv.weight)
+            gb = torch.empty(2 * self.cout, dtype=torch.float32, device=dev)
+            grads[id(rec.conv.bias)] = gb[:self.cout]
             # dgrad + wgrad + the bias sums of Reconstruction.pre in one pass over the HR activation
             gpb = torch.empty(r * r * h0, dtype=torch.float32, device=dev) if (self.blk <= 2 and h0 in (32, 64, 128)) else None
             if gpb is not None:
-                # order-independent sums (ops.head_conv_bwd_rows): dW and the bias sums land in zeroed f64 statistic buffers first
-                bw.sum64.zero_()
-                if getattr(bw, "dw64", None) is None or bw.dw64.numel() != ops.STAT_STRIPES * gw.numel():
-                    bw.dw64 = torch.zeros(ops.STAT_STRIPES * gw.numel(), dtype=torch.float64, device=dev)
+                # order-independent sums (ops.head_conv_bwd_rows): dW and the bias sums land in zeroed f64 statistic buffers first.  The
+                # three statistic buffers of this stretch (output-gradient sums, dW, pre's bias sums) are slices of ONE allocation: one
+                # memset and one batched fold instead of three each (these launches sit alone between the loss and the head's backward)
+                S = ops.STAT_STRIPES
+                sizes = (S * 2 * self.cout, S * gw.numel(), S * gpb.numel())
+                if getattr(bw, "h64", None) is None or bw.h64.numel() != sum(sizes):
+                    bw.h64 = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
                 else:
-                    bw.dw64.zero_()
-                ops.head_conv_bwd_rows(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, bw.dw64, bw.sum64, n, H, W, h0, self.cout, code)
-                ops.f64_to_f32(bw.dw64, gw)
-                ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * gpb.numel()], gpb)
+                    bw.h64.zero_()
+                s_out, dw64, s_pre = torch.split(bw.h64, sizes)
+                ops.channel_stats_nchw(dout, s_out, 128.0, 0.0)
+                ops.head_conv_bwd_rows(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, dw64, s_pre, n, H, W, h0, self.cout, code)
+                ops.f64_to_f32_batch([(s_out, gb, False), (dw64, gw.view(-1), False), (s_pre, gpb, False)])
             else:
+                bw.sum64.zero_()
+                ops.channel_stats_nchw(dout, bw.sum64, 128.0, 0.0)
+                ops.f64_to_f32(bw.sum64[:ops.STAT_STRIPES * 2 * self.cout], gb)
                 ops.head_conv_wgrad(dout, 128.0, pre_hr, self.blk, gw, n, H, W, h0, self.cout, code)
                 ops.head_conv_dgrad(dout, 128.0, rec.conv.weight, pre_hr, dpre_hr, self.blk, n, H, W, h0, self.cout, code)
         else:
@@ -810,13 +827,13 @@ class Engine:
         gb_pre[self.pre_perm_long] = gpb
         grads[id(rec.pre.bias)] = gb_pre
         self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
-        if not _ABLATE_XCOL:
+        if not _ABLATE_XCOL and "xwgrad" not in _ABL:
             self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
                         n_perm=self.pre_perm, hh=h, ww=w)
         self._ready(grads, list(rec.parameters()))
         cpre = self._convs[id(rec.pre)]
         ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
-        if not _ABLATE_XCOL:
+        if not _ABLATE_XCOL and "xdgrad" not in _ABL:
             # the 16-channel data gradient of the input source only feeds the input BatchNorm's parameter gradients at the very end of the
             # pass: on the second stream it is off the dependent chain (the two queues of the backward phase end within 0.1 ms of each
             # other, so this pays only together with something that lightens the weight-gradient queue: PSSR_XCOL_SIDE)
@@ -852,14 +869,27 @@ class Engine:
 
         def run():
             # the slot was zeroed with the whole flat buffer at the start of backward: accumulate (no separate zero pass)
-            ops.unpack_conv_wgrad(parts(), slot, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad, accumulate=True)
+            pr = parts()
+            if "unpack" not in _ABL:
+                ops.unpack_conv_wgrad(pr, slot, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad,
+                                      accumulate=not getattr(self, "_overwrite_grads", False))
         if self._side_on:
             self._on_side([dy], run)
         else:
             run()
 
-    def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c):
-        """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc."""
+    def _fused_dout(self, p, blk, kind):
+        """May relu_bwd_stats form the gradient of this block's output in its loader ('pool': skip + max-pool backward, 'unshuffle':
+        inverse pixel shuffle) instead of reading a tensor another launch wrote?  Plain ResBlocks in 16-bit storage with power-of-two
+        widths (PSSR_FUSE_DOUT=0: the separate launches, for A/B runs and the bit-identity test)."""
+        if getattr(blk, "a", None) is not None or not _FUSE_DOUT:
+            return False
+        return ops.relu_bwd_stats_fused_ok(p.code, blk.c, *p.dims[blk.level], unshuffle=kind == "unshuffle")
+
+    def _block_backward(self, p, bw, grads, blk, module, src, cin, first, out_buf, out_coff, dout, dsrc, dsrc_c, dout_from=None):
+        """dout: gradient of the block output (buffer at this level).  Writes the gradient of `src` into dsrc.
+        dout_from (16-bit storage): ("pool", dpool, dskip, dskip_coff) or ("unshuffle", dhi) -- `dout` was NOT materialised, relu_bwd_stats
+        forms it from these in its loader (_fused_dout)."""
         if getattr(blk, "a", None) is not None:
             from . import atrous as A
             A.ablock_backward(self, blk.a, module, grads, p.xin if first else src, 0, p.n, p.code, out_buf, out_coff, dout, 0, dsrc, not first)
@@ -879,13 +909,22 @@ class Engine:
         last = blk.bn[-1]
         bn_last = module.conv[3 * (nl - 1) + 1]
         self._before_write(dz)
-        ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
+        if "relustats" in _ABL:
+            pass
+        elif dout_from is None:
+            ops.relu_bwd_stats(dout, out_buf, blk.y[-1], last.mean, last.invstd, dz, last.bstats, npix, blk.c, code, out_coff=out_coff)
+        elif dout_from[0] == "pool":
+            ops.relu_bwd_stats_pool(dout_from[1], dout_from[2], dout_from[3], out_buf, out_coff, blk.y[-1], last.mean, last.invstd, dz, last.bstats,
+                                    n, hh, ww, blk.c, code)
+        else:
+            ops.relu_bwd_stats_unshuffle(dout_from[1], out_buf, out_coff, blk.y[-1], last.mean, last.invstd, dz, last.bstats, n, hh, ww, blk.c, code)
         dgam, dbet = self._gbuf(bn_last.weight), self._gbuf(bn_last.bias)
         self.bn_coefs(last.bstats, count, bn_last.weight, last.mean, last.invstd, last.ca, last.cb, last.cc, dgam, dbet)
         grads[id(bn_last.weight)], grads[id(bn_last.bias)] = dgam, dbet
         grads[id(module.respass.bias)] = dbet               # d(respass bias) = sum dz = dbeta of the last BN (copied by _ready)
         self._before_write(dy)
-        ops.bn_bwd_apply(dz, blk.y[-1], last.ca, last.cb, last.cc, dy, npix, blk.c, code)
+        if "apply" not in _ABL:
+            ops.bn_bwd_apply(dz, blk.y[-1], last.ca, last.cb, last.cc, dy, npix, blk.c, code)
         for k in range(nl - 1, 0, -1):
             conv = module.conv[3 * k]
             prev, bn_prev = blk.bn[k - 1], module.conv[3 * (k - 1) + 1]
@@ -904,7 +943,8 @@ class Engine:
             ri = (ri + 1) % len(ring)
             dy_nxt = ring[ri]
             self._before_write(dy_nxt)
-            ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_nxt, npix, blk.c, code)
+            if "apply" not in _ABL:
+                ops.bn_bwd_apply(g, blk.y[k - 1], prev.ca, prev.cb, prev.cc, dy_nxt, npix, blk.c, code)
             dy = dy_nxt
         conv0, rp = module.conv[0], module.respass
         if first:
@@ -935,6 +975,9 @@ class Engine:
         Lv, hid, r = self.L, self.hidden, self.r
         h0 = hid[0]
         grads = {}
+        plain = all(getattr(b, "a", None) is None for b in p.enc + p.dec) and p.epool is None and p.rpool is None
+        rows_head = ops.head_conv_supported(code, h0, self.cout) and self.blk <= 2 and h0 in (32, 64, 128)
+        self._overwrite_grads = plain and rows_head and not self.atrous and _OVERWRITE_GRADS
         self._begin_backward(dev)
         from . import atrous as A
         deep = p.epool_out if p.epool is not None else p.enc[Lv - 1].out
@@ -946,31 +989,43 @@ class Engine:
         else:
             self._head_backward(p, bw, grads, dout, feat, bw.dout[0])
         # ---- decoder, bottom-up in the data-flow sense (level 0 first)
+        unshuf = None               # set when the next block up reads its output gradient straight out of dcat (no inverse-shuffle launch)
         for l in range(0, Lv - 1):
             blk = p.dec[l]
             self._block_backward(p, bw, grads, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False,
-                                 blk.out, 0, bw.dout[l], bw.dcat[l], hid[l + 1] // 4 + hid[l])
+                                 blk.out, 0, bw.dout[l], bw.dcat[l], hid[l + 1] // 4 + hid[l], dout_from=unshuf)
             # split dcat: [0, h_{l+1}/4) -> un-shuffle to the producer at level l+1
-            ops.pixel_shuffle(bw.dout[l + 1], bw.dcat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code, inverse=True)
+            nxt = p.dec[l + 1] if l + 1 < Lv - 1 else p.enc[Lv - 1]
+            if (l + 1 < Lv - 1 or p.epool is None) and self._fused_dout(p, nxt, "unshuffle"):
+                unshuf = ("unshuffle", bw.dcat[l])
+            else:
+                unshuf = None
+                if "unshuf" not in _ABL:
+                    ops.pixel_shuffle(bw.dout[l + 1], bw.dcat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code, inverse=True)
         if p.epool is not None:         # bw.dout[Lv-1] is the gradient of the pooled map: back through the PSP block
             A.psp_backward(self, p.epool, m.encoder_pool, grads, p.enc[Lv - 1].out, 0, n, code, p.epool_out, 0, bw.dout[Lv - 1], 0, bw.depool, 0)
             bw.dout[Lv - 1], bw.depool = bw.depool, bw.dout[Lv - 1]
         # ---- encoder, deepest first
         for i in range(Lv - 1, -1, -1):
             blk = p.enc[i]
+            dfrom = None
             if i < Lv - 1:
                 off = hid[i + 1] // 4
                 # block output feeds the pool (dpooled) and the skip (dcat slice)
-                ops.maxpool2_bwd(p.cat[i], bw.dpooled[i], bw.dcat[i], bw.dout[i], n, *p.dims[i], hid[i], code,
-                                 act_coff=off, dskip_coff=off)
+                if self._fused_dout(p, blk, "pool"):
+                    dfrom = ("pool", bw.dpooled[i], bw.dcat[i], off)
+                elif "poolbwd" not in _ABL:
+                    ops.maxpool2_bwd(p.cat[i], bw.dpooled[i], bw.dcat[i], bw.dout[i], n, *p.dims[i], hid[i], code,
+                                     act_coff=off, dskip_coff=off)
                 out_buf, out_off = p.cat[i], off
             else:
                 out_buf, out_off = blk.out, 0
+                dfrom = unshuf if Lv > 1 else None
             if i == 0:
                 src, cin, dsrc, dsrc_c = p.xcol, self.xc, bw.dxcol_a, self.xc
             else:
                 src, cin, dsrc, dsrc_c = p.pooled[i - 1], ops.pad_to(hid[i - 1], 16), bw.dpooled[i - 1], hid[i - 1]
-            self._block_backward(p, bw, grads, blk, m.encoder[i], src, cin, i == 0, out_buf, out_off, bw.dout[i], dsrc, dsrc_c)
+            self._block_backward(p, bw, grads, blk, m.encoder[i], src, cin, i == 0, out_buf, out_off, bw.dout[i], dsrc, dsrc_c, dout_from=dfrom)
             if split_cb is not None and i == Lv - 1 and Lv > 1:
                 self._flush_folds()
                 self._flush_moves()

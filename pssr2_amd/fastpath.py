@@ -396,6 +396,7 @@ class TrainStepper:
         self.graph = self.graph2 = None
         self.split, self.eager_only = False, True
         self.engine.reset_backward_state()
+        self.engine.mark_weights_changed()      # the aborted capture marked packed weights / folded BatchNorms fresh without running their kernels
         for p in self.model.parameters():
             p.grad = None
         torch.cuda.synchronize()
@@ -516,6 +517,7 @@ class EvalStepper:
                 print(f"[pssr2_amd] the evaluation pass could not be captured into a hipGraph ({type(e).__name__}: {e}); "
                       "running it launch by launch", flush=True)
                 self.eager_only = True
+                self.engine.mark_weights_changed()      # (the aborted capture marked caches fresh without running their kernels)
                 torch.cuda.synchronize()
         if self.eager_only:
             if self.weights_move:

@@ -205,6 +205,23 @@ def relu_bwd_stats(dout, out, y, mean, invstd, dz, stats, npix, c, dtype, out_co
                                         L.ptr(stats), C.c_int64(npix), c, dtype, L.stream_ptr()), "pssr_relu_bwd_stats")
 
 
+def relu_bwd_stats_fused_ok(dtype, c, h=2, w=2, unshuffle=False):
+    """The loader-fused forms below take 16-bit storage and power-of-two channel counts (every BatchNorm of the default models)."""
+    return dtype != L.F32 and (c & (c - 1)) == 0 and c >= (32 if unshuffle else 8) and (unshuffle or (h % 2 == 0 and w % 2 == 0))
+
+
+def relu_bwd_stats_pool(dpool, dskip, dskip_coff, out, out_coff, y, mean, invstd, dz, stats, n, h, w, c, dtype):
+    """relu_bwd_stats whose d(out) = dskip + max-pool-backward(dpool) is formed in the loader (no maxpool2_bwd launch, no d(out) tensor)."""
+    L.check(L.lib().pssr_relu_bwd_stats_pool(*_ref(dpool), *_ref(dskip, dskip_coff), *_ref(out, out_coff), *_ref(y), L.ptr(mean), L.ptr(invstd),
+                                             *_ref(dz), L.ptr(stats), n, h, w, c, dtype, L.stream_ptr()), "pssr_relu_bwd_stats_pool")
+
+
+def relu_bwd_stats_unshuffle(dhi, out, out_coff, y, mean, invstd, dz, stats, n, h, w, c, dtype):
+    """relu_bwd_stats whose d(out) is the inverse pixel shuffle (r = 2) of channels [0, c / 4) of ``dhi`` (twice the resolution)."""
+    L.check(L.lib().pssr_relu_bwd_stats_unshuffle(*_ref(dhi), *_ref(out, out_coff), *_ref(y), L.ptr(mean), L.ptr(invstd), *_ref(dz), L.ptr(stats),
+                                                  n, h, w, c, dtype, L.stream_ptr()), "pssr_relu_bwd_stats_unshuffle")
+
+
 def channel_sum_nhwc(x, npix, c, out, dtype, coff=0, cstride=None):
     cs = x.shape[-1] if cstride is None else cstride
     L.check(L.lib().pssr_channel_sum_nhwc(L.ptr(x), cs, coff, C.c_int64(npix), c, L.ptr(out), dtype, L.stream_ptr()),

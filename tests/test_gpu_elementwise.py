@@ -75,3 +75,74 @@ def test_copy_f32_batch():
         ops.copy_f32_batch([(dsts[0], srcs[1])])
     with pytest.raises(ValueError):
         ops.copy_f32_batch([(dsts[0].double(), srcs[0].double())])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 8, 12, 64, 16), (3, 4, 6, 8, 0), (1, 16, 16, 256, 64)])
+def test_relu_bwd_stats_with_maxpool_backward_in_the_loader(case, dt):
+    """pssr_relu_bwd_stats_pool == pssr_maxpool2_bwd followed by pssr_relu_bwd_stats: dz bit for bit (the pooled + skip gradient is rounded to
+    the storage type where the separate kernel stored it), statistics to summation order.  Ties inside a window (ReLU zeros) are what the
+    first-maximum rule is about: the activations are post-ReLU, a third of them zero."""
+    from pssr2_amd import ops
+    n, h, w, c, off = case
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(sum(case))
+    cs = off + c + 8
+    act = torch.zeros(n, h, w, cs, dtype=dt, device="cuda")
+    act[..., off:off + c] = torch.relu(torch.randn(n, h, w, c, generator=g) - 0.4).to(dt).cuda()
+    dskip = torch.zeros(n, h, w, cs, dtype=dt, device="cuda")
+    dskip[..., off:off + c] = torch.randn(n, h, w, c, generator=g).to(dt).cuda()
+    dpool = torch.randn(n, h // 2, w // 2, c, generator=g).to(dt).cuda()
+    y = torch.randn(n, h, w, c, generator=g).to(dt).cuda()
+    mean, invstd = torch.randn(c, generator=g).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
+    npix = n * h * w
+    dout = torch.empty(n, h, w, c, dtype=dt, device="cuda")
+    ops.maxpool2_bwd(act, dpool, dskip, dout, n, h, w, c, code, act_coff=off, dskip_coff=off)
+    dz0 = torch.empty(n, h, w, c, dtype=dt, device="cuda")
+    st0 = torch.zeros(ops.STAT_STRIPES * 2 * c, dtype=torch.float64, device="cuda")
+    ops.relu_bwd_stats(dout, act, y, mean, invstd, dz0, st0, npix, c, code, out_coff=off)
+    dz1 = torch.full_like(dz0, 9.0)
+    st1 = torch.zeros_like(st0)
+    assert ops.relu_bwd_stats_fused_ok(code, c, h, w)
+    ops.relu_bwd_stats_pool(dpool, dskip, off, act, off, y, mean, invstd, dz1, st1, n, h, w, c, code)
+    assert torch.equal(dz1, dz0)
+    a, b = (s.view(ops.STAT_STRIPES, 2, c).sum(0).cpu().numpy() for s in (st0, st1))
+    np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-4 * npix ** 0.5)
+    # and against torch: max_pool2d's own backward + the skip, then the ReLU mask
+    av = act[..., off:off + c].float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    F.max_pool2d(av, 2).backward(dpool.float().cpu().permute(0, 3, 1, 2))
+    want = (av.grad.permute(0, 2, 3, 1) + dskip[..., off:off + c].float().cpu()).to(dt)
+    want = torch.where(act[..., off:off + c].cpu().float() > 0, want.float(), torch.zeros(())).to(dt)
+    assert torch.equal(dz1.cpu(), want)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 4, 6, 128, 0), (1, 8, 8, 32, 16), (2, 2, 4, 1024, 0)])
+def test_relu_bwd_stats_with_inverse_pixel_shuffle_in_the_loader(case, dt):
+    """pssr_relu_bwd_stats_unshuffle == pssr_pixel_shuffle(inverse) followed by pssr_relu_bwd_stats: dz bit for bit, statistics to
+    summation order; the high-resolution gradient is the first c / 4 channels of a wider concat-buffer gradient."""
+    from pssr2_amd import ops
+    n, h, w, c, out_off = case
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(sum(case))
+    dhi = torch.randn(n, 2 * h, 2 * w, c // 4 + 24, generator=g).to(dt).cuda()
+    out = torch.zeros(n, h, w, out_off + c, dtype=dt, device="cuda")
+    out[..., out_off:] = torch.relu(torch.randn(n, h, w, c, generator=g)).to(dt).cuda()
+    y = torch.randn(n, h, w, c, generator=g).to(dt).cuda()
+    mean, invstd = torch.randn(c, generator=g).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
+    npix = n * h * w
+    dout = torch.empty(n, h, w, c, dtype=dt, device="cuda")
+    ops.pixel_shuffle(dout, dhi, n, h, w, c // 4, 2, code, inverse=True)
+    dz0 = torch.empty(n, h, w, c, dtype=dt, device="cuda")
+    st0 = torch.zeros(ops.STAT_STRIPES * 2 * c, dtype=torch.float64, device="cuda")
+    ops.relu_bwd_stats(dout, out, y, mean, invstd, dz0, st0, npix, c, code, out_coff=out_off)
+    dz1 = torch.full_like(dz0, 9.0)
+    st1 = torch.zeros_like(st0)
+    assert ops.relu_bwd_stats_fused_ok(code, c, unshuffle=True)
+    ops.relu_bwd_stats_unshuffle(dhi, out, out_off, y, mean, invstd, dz1, st1, n, h, w, c, code)
+    assert torch.equal(dz1, dz0)
+    a, b = (s.view(ops.STAT_STRIPES, 2, c).sum(0).cpu().numpy() for s in (st0, st1))
+    np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-4 * npix ** 0.5)
+    want = F.pixel_unshuffle(dhi[..., :c // 4].float().cpu().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    want = torch.where(out[..., out_off:].cpu().float() > 0, want, torch.zeros(())).to(dt)
+    assert torch.equal(dz1.cpu(), want)
