@@ -1084,138 +1084,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_1x1_kernel(const WgradArg
         }
 }
 
-// -----------------------------------------------------------------------------------------------------------------
-// All-DMA 1x1 weight gradient for prologue-free, plainly laid out operands (round 4).  What bounded the kernel above on RDNet's
-// bottleneck layers (conv1: C -> 4C on the LayerNorm output; MFMA busy 0.06-0.07 in profiles/r03_conv_pmc.txt) is not the matrix pipe but
-// the bytes a 128 x 128 slab pulls per multiply -- 512 B of staging per MFMA, every byte through a staging register and a 13-cycle
-// ds_write_b128 -- and the re-reads a small slab implies (conv1 of the 64^2 stage: dz read twice, the input eight times: 1.07 GB).
-// Here a workgroup owns a 256 (cout) x 128 (cin) slab, a wave 128 x 64 of it (4 x 2 MFMA tiles, 128 accumulators: two workgroups per
-// CU), and the pixel dimension is walked in stages of 32 pixels that go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`) into a
-// ring of three 24 KiB buffers: stage i + 2 is requested behind the barrier that publishes stage i, so one barrier per stage orders
-// both the landing of the pieces and the reuse of the buffer (every wave passed the barrier = every wave has consumed stage i - 1).
-// Pixels are a flat index (dy_blk = in_blk = 0): the buffer resource of a stage starts at its first pixel and ends with the tensor, so
-// the last, partial stage and the channel tails are zero-filled by the out-of-range rule (no memory access).  Six 1 KiB pieces per
-// wave and stage (piece = 16 pixels x 64 B of one 32-channel sub-tile, lane l -> pixel l / 4, 16 bytes l % 4), 16 MFMAs per wave and
-// stage from 12 transposed fragment reads.  Partial slabs leave as in the kernel above (fixed-order reduction by unpack9_kernel<1>).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad16_1x1d_kernel(const WgradArgs p, long npix) {
-    using X = TT<T>;
-    static_assert(sizeof(T) == 2, "16-bit types");
-    constexpr int EPS = 8, ESZ = 2, ROWB = 64;
-    constexpr int PT = 32;                                          // pixels per stage
-    constexpr int CO_S = 8, CI_S = 4;                               // 32-channel sub-tiles of the slab
-    constexpr int DY_BYTES = CO_S * PT * ROWB, X_BYTES = CI_S * PT * ROWB, BUF = DY_BYTES + X_BYTES;
-    constexpr int DY_PCS = DY_BYTES / 1024, PCS = BUF / 1024, PW = PCS / 4, NB = 3;
-    static_assert(PW == 6 && PCS % 4 == 0, "pieces per wave");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, kw = wave >> 1;                        // 128-row half, 64-column half of the slab
-    const int ct = blockIdx.y;
-    const int n0 = (ct % p.co_tiles) * 256, k0 = (ct / p.co_tiles) * 128;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    // stage-independent piece descriptors: piece q = wave + 4 j lands at LDS byte q * 1024 of the stage's buffer
-    unsigned voff[PW];
-    const int lp = lane >> 2, pin = lane & 3;
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        const int q = wave + 4 * j;
-        if (q < DY_PCS) {
-            const int ch = n0 + (q >> 1) * 32 + pin * EPS, px = (q & 1) * 16 + lp;
-            voff[j] = ch < p.cout ? (unsigned)((px * p.dy_cs + ch) * ESZ) : 0xffffffffu;
-        } else {
-            const int qa = q - DY_PCS;
-            const int ch = k0 + (qa >> 1) * 32 + pin * EPS, px = (qa & 1) * 16 + lp;
-            voff[j] = ch < p.cin_pad ? (unsigned)((px * p.in_cs + ch) * ESZ) : 0xffffffffu;
-        }
-    }
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const char* const dy_base = (const char*)p.dy + (long)p.dy_co * ESZ;
-    const char* const in_base = (const char*)p.in + (long)p.in_co * ESZ;
-    const long dy_bytes = npix * p.dy_cs * ESZ, in_bytes = npix * p.in_cs * ESZ;       // (the last pixel's row may end short of cs: the
-                                                                                        // channel test above keeps every live lane inside)
-    // fragment read bases (buffer 0): ds_read_b64_tr_b16, lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
-    const int g = lane >> 4, li = lane & 15, qr = li >> 2, pcol = li & 3;
-    const int fr_off = ((g >> 1) * 8 + qr) * ROWB + ((g & 1) * 16 + pcol * 4) * 2;
-    const char* const dy_rd0 = smem + (4 * cw) * PT * ROWB + fr_off;
-    const char* const x_rd0 = smem + DY_BYTES + (2 * kw) * PT * ROWB + fr_off;
-
-#define W1D_ISSUE(STAGE, B)                                                                                       \
-    {                                                                                                             \
-        const long p0_ = (long)(STAGE) * PT;                                                                      \
-        const long o_dy_ = p0_ * p.dy_cs * ESZ, o_in_ = p0_ * p.in_cs * ESZ;                                      \
-        const long r_dy_ = dy_bytes - o_dy_, r_in_ = in_bytes - o_in_;                                            \
-        const __amdgpu_buffer_rsrc_t rdy_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
-            (void*)(dy_base + o_dy_), 0, (int)(unsigned)(r_dy_ < 0xfffffff0L ? r_dy_ : 0xfffffff0L), 0x00020000); \
-        const __amdgpu_buffer_rsrc_t rin_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
-            (void*)(in_base + o_in_), 0, (int)(unsigned)(r_in_ < 0xfffffff0L ? r_in_ : 0xfffffff0L), 0x00020000); \
-        const unsigned lb_ = lds0 + (unsigned)(B) * BUF + (unsigned)wave * 1024u;                                 \
-        _Pragma("unroll") for (int j = 0; j < PW; ++j) {                                                          \
-            const unsigned la_ = __builtin_amdgcn_readfirstlane(lb_ + (unsigned)j * 4096u);                       \
-            if (wave + 4 * j < DY_PCS)                                                                            \
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la_), "v"(voff[j]), "s"(rdy_) : "memory"); \
-            else                                                                                                  \
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la_), "v"(voff[j]), "s"(rin_) : "memory"); \
-        }                                                                                                         \
-    }
-
-    const int n_st = p.n_tiles;                                     // stages of the launch; this workgroup takes blockIdx.x, + split, ...
-    int st = blockIdx.x, buf = 0;
-    if (st < n_st) W1D_ISSUE(st, 0)
-    if (st + p.split < n_st) W1D_ISSUE(st + p.split, 1)
-    for (; st < n_st; st += p.split) {
-        // this wave's pieces of stage `st` have landed (the six of the next stage may still be in flight) ...
-        if (st + p.split < n_st) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and so have every other wave's; every wave has also finished reading the stage before (its buffer is requested next)
-        asm volatile("s_barrier" ::: "memory");
-        const int nb2 = buf + 2 >= NB ? buf + 2 - NB : buf + 2;
-        if (st + 2 * p.split < n_st) W1D_ISSUE(st + 2 * p.split, nb2)
-        const char* const dy_rd = dy_rd0 + buf * BUF;
-        const char* const x_rd = x_rd0 + buf * BUF;
-#pragma unroll
-        for (int s = 0; s < PT / 16; ++s) {
-            u32x4 af[4], bf[2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = Frag16::load(dy_rd + a * PT * ROWB + s * 16 * ROWB, dy_rd + a * PT * ROWB + (s * 16 + 4) * ROWB);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = Frag16::load(x_rd + b * PT * ROWB + s * 16 * ROWB, x_rd + b * PT * ROWB + (s * 16 + 4) * ROWB);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) X::mma(acc[a][b], af[a], bf[b]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (fragment reads retired before this wave can reach the next barrier)
-        buf = buf + 1 >= NB ? 0 : buf + 1;
-    }
-#undef W1D_ISSUE
-    float* dst = p.dw + (p.parts > 0 ? (long)blockIdx.x * p.part_stride : 0L);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int kcol = k0 + (2 * kw + b) * 32 + (lane & 31);
-            if (kcol >= p.cin_pad) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + (4 * cw + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (n < p.cout) {
-                    float* qd = dst + (long)n * p.cin_pad + kcol;
-                    if (p.parts > 0) *qd = acc[a][b][e];
-                    else atomicAdd(qd, acc[a][b][e]);
-                }
-            }
-        }
-}
-
 // full tiles and offsets within the bias window: what the lean-loader kernels need (same answer at query and launch time)
 template <int GEO> bool wg_lean_ok(const WgradArgs& p) {
     constexpr int TWL = WGeo<GEO>::TWL, THL = WGeo<GEO>::THL;
@@ -1260,47 +1128,6 @@ int launch_1x1(WgradArgs p, hipStream_t stream, int* query) {
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_wgrad16_1x1_kernel<T, GEO>), dim3(split, slabs), dim3(256), LDS, stream, p);
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
-
-// conv_wgrad16_1x1d_kernel: 16-bit, one tap, no prologue, flat pixel order, both tensors within the 4 GB reach of a buffer resource
-inline bool wg_1x1d_ok(const WgradArgs& p) {
-    const long npix = (long)p.N * p.H * p.W;
-    return pssr_tunables().wgrad_dma && p.taps == 1 && p.prologue == PSSR_PRO_NONE && p.dy_blk == 0 && p.in_blk == 0 && p.cout > 32 && p.cin_pad > 32 &&
-           npix * p.dy_cs * 2 < (1L << 32) - 64 && npix * p.in_cs * 2 < (1L << 32) - 64 && npix >= 32;
-}
-
-template <typename T>
-int launch_1x1d(WgradArgs p, hipStream_t stream, int* query) {
-    constexpr int LDS = 3 * (8 + 4) * 32 * 64;
-    const long npix = (long)p.N * p.H * p.W;
-    p.n_tiles = (int)((npix + 31) / 32);                 // stages of 32 pixels
-    p.co_tiles = cdiv(p.cout, 256); p.ci_tiles = cdiv(p.cin_pad, 128);
-    const int slabs = p.co_tiles * p.ci_tiles;
-    int split;
-    if (query != nullptr || p.parts > 0) {
-        split = cdiv(pssr_tunables().wgrad_blocks_1x1, slabs);
-        if (split > p.n_tiles) split = p.n_tiles;
-        if (split < 1) split = 1;
-        if (query != nullptr) { *query = split; return PSSR_OK; }
-        PSSR_CHECK(p.parts == split, PSSR_ERR_ARG, "wgrad: dw_parts=%d but this shape needs %d (ask pssr_conv2d_wgrad_parts)", p.parts, split);
-        p.part_stride = (long)p.cout * p.cin_pad;
-    } else {
-        split = p.n_tiles / 8;
-        if (split > cdiv(1024, slabs)) split = cdiv(1024, slabs);
-        if (slabs * split < 512) split = cdiv(512, slabs);
-        if (split > p.n_tiles) split = p.n_tiles;
-        if (split < 1) split = 1;
-        p.part_stride = 0;
-    }
-    p.split = split;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad16_1x1d_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((conv_wgrad16_1x1d_kernel<T>), dim3(split, slabs), dim3(256), LDS, stream, p, npix);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }
@@ -1414,7 +1241,6 @@ template <typename T>
 int launch_shape(const WgradArgs& a, hipStream_t s, int* query) {
     if constexpr (sizeof(T) == 2) {
         // 1x1 with both channel counts beyond one 32-wide sub-tile: the 128 x 128 slab kernel (lean-loader launches only)
-        if (wg_1x1d_ok(a)) return launch_1x1d<T>(a, s, query);
         if (a.taps == 1 && a.cout > 32 && a.cin_pad > 32) {
             if (a.W > 8 && wg_lean_ok<0>(a)) return launch_1x1<T, 0>(a, s, query);
             if (a.W > 4 && a.W <= 8 && wg_lean_ok<1>(a)) return launch_1x1<T, 1>(a, s, query);

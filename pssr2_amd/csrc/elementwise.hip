@@ -659,6 +659,92 @@ __global__ __launch_bounds__(TPB) void relu_bwd_stats8_unshuffle_kernel(Ref dhi,
     }
 }
 
+// Per-channel sums over the border pixels of every image of an NHWC tensor: out[kind][c], kind 0 = top row (y = 0), 1 = bottom row,
+// 2 = left column (x = 0), 3 = right column, 4-7 = the corners (0,0), (0,w-1), (h-1,0), (h-1,w-1).  A workgroup owns 64 channels (one
+// 128-byte line per pixel in 16-bit storage) of one kind: thread = (pixel lane t / 8, 8-channel piece t % 8), fixed summation order
+// (per-thread stride loop, then a tree over the 32 pixel lanes): bit-reproducible.  Used by the input-BatchNorm gradient below.
+template <typename T>
+__global__ __launch_bounds__(TPB) void border_sums_kernel(Ref x, int n, int h, int w, int c, float* __restrict__ out) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    __shared__ float lds[32][8][8];
+    const int kind = blockIdx.y, c0 = blockIdx.x * 64 + (threadIdx.x & 7) * 8, pl = threadIdx.x >> 3;
+    const int len = kind < 2 ? w : kind < 4 ? h : 1;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < c)
+        for (int i = pl; i < n * len; i += 32) {
+            const int img = i / len, j = i - img * len;
+            int py, px;
+            if (kind == 0) { py = 0; px = j; } else if (kind == 1) { py = h - 1; px = j; }
+            else if (kind == 2) { py = j; px = 0; } else if (kind == 3) { py = j; px = w - 1; }
+            else { py = (kind & 2) ? h - 1 : 0; px = (kind & 1) ? w - 1 : 0; }
+            float v[8];
+            X::unpack(*(const u32x4*)at<T>(x, ((long)img * h + py) * w + px, c0), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pl][threadIdx.x & 7][e] = acc[e];
+    __syncthreads();
+    for (int o = 16; o > 0; o >>= 1) {
+        if (pl < o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds[pl][threadIdx.x & 7][e] += lds[pl + o][threadIdx.x & 7][e];
+        __syncthreads();
+    }
+    if (pl == 0 && c0 < c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[(long)kind * c + c0 + e] = lds[0][threadIdx.x & 7][e];
+}
+
+// Input-BatchNorm statistics [sum g, sum g * xhat] of the part of d(xn) that arrives through Reconstruction.pre's input-channel source,
+// WITHOUT the 16-channel data gradient d(xcol) = W1^T d(pre) (a pass over the 1 GB d(pre) tensor for two scalars per channel).  With
+// xcol[q][ch*9+t] = xn[q + off_t] inside the image and 0 outside (xn = gamma * xhat + beta):
+//   sum g        = sum_{o,t} W1[o][t] * (sum over the pixels q with q + off_t inside of d(pre)[q][o])
+//                = sum_{o,t} W1[o][t] * (S[o] - rows/columns of the border that tap t excludes + the corner counted twice)
+//   sum g * xhat = (sum_{o,t} W1[o][t] * dW1[o][t] - beta * sum g) / gamma        (dW1 = d(pre)^T xcol is the weight gradient of that source)
+// S = bias-gradient sums of pre, borders = border_sums_kernel(d(pre)), both in pre's stored channel order n' = sub * h0 + c of weight row
+// o = c * r2 + sub.  One workgroup; f64 accumulation in a fixed order; the result is added to stripe 0 of the statistic rows.
+__global__ __launch_bounds__(TPB) void input_norm_pre_stats_kernel(const float* __restrict__ wgt, const float* __restrict__ dwg, int cout, int cin_w, int ci0,
+                                                                   int cin, int h0, int r2, const float* __restrict__ S, const float* __restrict__ B,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, double* stats) {
+    __shared__ double red[2][TPB];
+    for (int ch = 0; ch < cin; ++ch) {
+        double s1 = 0.0, a = 0.0;
+        for (int o = threadIdx.x; o < cout; o += TPB) {
+            const int np = (o % r2) * h0 + o / r2;
+            const float* wr = wgt + ((long)o * cin_w + ci0 + ch) * 9;
+            const float* dr = dwg + ((long)o * cin_w + ci0 + ch) * 9;
+            const double s = S[np];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t % 3;
+                double st = s;
+                if (ky == 0) st -= B[0 * cout + np];
+                if (ky == 2) st -= B[1 * cout + np];
+                if (kx == 0) st -= B[2 * cout + np];
+                if (kx == 2) st -= B[3 * cout + np];
+                if (ky != 1 && kx != 1) st += B[(4 + (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0)) * cout + np];
+                s1 += (double)wr[t] * st;
+                a += (double)wr[t] * (double)dr[t];
+            }
+        }
+        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = a;
+        __syncthreads();
+        for (int o = TPB / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double g1 = red[0][0];
+            const double g2 = (red[1][0] - (double)beta[ch] * g1) / (double)gamma[ch];
+            stat_add(stats + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g1);
+            stat_add(stats + cin + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g2);
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ void channel_sum_kernel(Ref x, double* out, long npix, int c, ChanMap m) {
     __shared__ float lds[TPB * 4];
@@ -796,6 +882,30 @@ int pssr_input_norm_bwd2(const void* dxcol_a, const void* dxcol_b, int xc, const
     if (gx > 512) gx = 512;
     DISPATCH_T(dtype, hipLaunchKernelGGL(input_norm_bwd_kernel<T>, dim3(gx, c), dim3(TPB), 0, (hipStream_t)s, (const T*)dxcol_a, (const T*)dxcol_b, xc,
                                          (const T*)dpatch, pc, patch > 0 ? patch : 1, x, pre_scale, pre_shift, mean, invstd, n, c, h, w, stats));
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_border_sums_nhwc(const void* x, int cs, int co, int n, int h, int w, int c, float* out, int dtype, pssr_stream_t s) {
+    PSSR_CHECK(x && out && n > 0 && h > 0 && w > 0 && c > 0, PSSR_ERR_ARG, "border_sums: bad args");
+    PSSR_CHECK(dtype == PSSR_BF16 || dtype == PSSR_F16, PSSR_ERR_UNSUPPORTED, "border_sums: 16-bit storage only (dtype %d)", dtype);
+    PSSR_CHECK(c % 8 == 0 && cs % 8 == 0 && co % 8 == 0 && co + c <= cs, PSSR_ERR_ARG, "border_sums: channel layout (%d,%d,%d)", cs, co, c);
+    if (dtype == PSSR_BF16)
+        hipLaunchKernelGGL(border_sums_kernel<bf16_t>, dim3((c + 63) / 64, 8), dim3(TPB), 0, (hipStream_t)s, Ref{x, cs, co}, n, h, w, c, out);
+    else
+        hipLaunchKernelGGL(border_sums_kernel<f16_t>, dim3((c + 63) / 64, 8), dim3(TPB), 0, (hipStream_t)s, Ref{x, cs, co}, n, h, w, c, out);
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_input_norm_pre_stats(const float* weight, const float* dweight, int cout, int cin_w, int ci_begin, int cin, int h0, int r2,
+                              const float* bias_sums, const float* border_sums, const float* gamma, const float* beta, double* stats,
+                              pssr_stream_t s) {
+    PSSR_CHECK(weight && dweight && bias_sums && border_sums && gamma && beta && stats, PSSR_ERR_ARG, "input_norm_pre_stats: null pointer");
+    PSSR_CHECK(cout > 0 && cin > 0 && ci_begin >= 0 && ci_begin + cin <= cin_w && h0 > 0 && r2 > 0 && cout == h0 * r2, PSSR_ERR_ARG,
+               "input_norm_pre_stats: shape (cout %d, cin %d+%d of %d, h0 %d, r2 %d)", cout, ci_begin, cin, cin_w, h0, r2);
+    hipLaunchKernelGGL(input_norm_pre_stats_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)s, weight, dweight, cout, cin_w, ci_begin, cin, h0, r2,
+                       bias_sums, border_sums, gamma, beta, stats);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -541,17 +541,19 @@ class RDEngine(Engine):
         for k in range(nd - 1, -1, -1):
             blk = p.dec[k]
             rr = m.ratios[k + 1]
-            if k + 1 < nd:
-                ops.pixel_shuffle(bw.dout[k], bw.dcat[k + 1], n, *p.dims[k], hid[k] // (rr * rr), rr, code, inverse=True)
+            dhi = bw.dcat[k + 1] if k + 1 < nd else bw.dfeat
+            dfrom = None
+            if rr == 2 and self._fused_dout(p, blk, "unshuffle"):
+                dfrom = ("unshuffle", dhi)          # relu_bwd_stats reads the block's output gradient out of the finer level's buffer
             else:
-                ops.pixel_shuffle(bw.dout[k], bw.dfeat, n, *p.dims[k], h0, rr, code, inverse=True)
+                ops.pixel_shuffle(bw.dout[k], dhi, n, *p.dims[k], hid[k] // (rr * rr) if k + 1 < nd else h0, rr, code, inverse=True)
             if k == 0 and p.epool is not None:
                 self._block_backward(p, bw, grads, blk, m.decoder[k], p.epool_out, p.epool_out.shape[-1], False, blk.out, 0, bw.dout[k], bw.depool,
-                                     m.skips[0])
+                                     m.skips[0], dout_from=dfrom)
                 A.psp_backward(self, p.epool, m.encoder_pool, grads, p.cat[0], 0, n, code, p.epool_out, 0, bw.depool, 0, bw.dcat[0], 0)
             else:
                 self._block_backward(p, bw, grads, blk, m.decoder[k], p.cat[k], p.cat[k].shape[-1], False, blk.out, 0, bw.dout[k], bw.dcat[k],
-                                     p.shuf_c[k] + m.skips[k])
+                                     p.shuf_c[k] + m.skips[k], dout_from=dfrom)
         if split_cb is not None:       # reconstruction + decoder gradients (the tail of the flat buffer) are final
             self._flush_folds()
             self._flush_moves()
@@ -598,9 +600,13 @@ class RDEngine(Engine):
             return self._finish_backward(grads)
         # ---- input BatchNorm parameters (gradient sources: head im2col + stem patches)
         stn = p.bn_in
-        stn.bstats.zero_()
-        self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream: Engine._head_backward)
-        ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
+        if getattr(self, "xcol_linear", False):     # the head's share was added behind pre's weight gradient (Engine._head_backward)
+            self._before_write(stn.bstats)
+            ops.input_norm_bwd2(None, None, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
+        else:
+            stn.bstats.zero_()
+            self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream: Engine._head_backward)
+            ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         self.bn_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet

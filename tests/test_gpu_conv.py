@@ -297,58 +297,6 @@ def test_conv_wgrad_all_dma_kernel(case, dt):
     assert torch.equal(p1, p0) and torch.equal(dw1, dw0)
 
 
-WG1D_CASES = [
-    # n, cin, cout, h, w: 1x1, prologue-free (what conv_wgrad16_1x1d_kernel serves: 256 x 128 slabs, stages of 32 flat pixels)
-    (2, 128, 256, 16, 16),     # one full slab, 16 stages
-    (4, 208, 72, 16, 32),      # channel tails on both sides (cout 72 < 256, cin 208 = 128 + 80)
-    (3, 160, 640, 8, 8),       # RDNet-like: 3 cout tiles (640 = 2 x 256 + 128), 2 cin tiles; 6 stages
-    (1, 64, 48, 5, 7),         # 35 pixels: the second stage is partial (3 pixels, the rest zero-filled out of range)
-    (6, 320, 1056, 32, 32),    # many stages per workgroup: the ring of three in rotation; cout tail of 32
-    (2, 48, 80, 4, 4),         # exactly one stage
-]
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", WG1D_CASES)
-def test_conv_wgrad_1x1_all_dma_kernel(case, dt):
-    """Prologue-free 1x1 weight gradient through the all-DMA kernel (round 4; tunable WGRAD_DMA) against torch's conv2d_weight on the same
-    16-bit operands and against the register-staged 128 x 128 kernel, in partial-slab and in atomic mode; operands are channel slices of
-    wider buffers (stride / offset handling of the flat pixel walk)."""
-    from pssr2_amd import ops, _lib as L
-    n, cin, cout, h, w = case
-    g = torch.Generator().manual_seed(sum(case))
-    code = ops.dtype_code(dt)
-    a = torch.randn(n, cin, h, w, generator=g).to(dt).float()
-    dy = torch.randn(n, cout, h, w, generator=g).to(dt).float()
-    ref = torch.nn.grad.conv2d_weight(a, (cout, cin, 1, 1), dy)
-    cpad, copad = ops.pad_to(cin, 16), ops.pad_to(cout, 16)
-    xa = torch.full((n, h, w, cpad + 32), 3.0, dtype=dt, device="cuda")           # the operand sits at channel offset 16 of a wider buffer
-    xa[..., 16:16 + cpad] = _nhwc(a, cpad, dt)
-    dyb = torch.full((n, h, w, copad + 16), -2.0, dtype=dt, device="cuda")
-    dyb[..., 8:8 + copad] = _nhwc(dy, copad, dt)
-
-    def run(dma):
-        old = L.lib().pssr_set_option(b"WGRAD_DMA", dma)
-        try:
-            parts = ops.conv2d_wgrad_parts(dyb, cout, xa, cpad, 1, n=n, h=h, w=w, dtype=code, dy_coff=8, in_coff=16)
-            dw = torch.full((cout, cin, 1, 1), 9.0, device="cuda")
-            ops.unpack_conv_wgrad(parts, dw, k_pad=cpad)
-            dwa = torch.zeros(cout, 1, cpad, device="cuda")
-            ops.conv2d_wgrad(dyb, cout, xa, cpad, 1, dwa, n=n, h=h, w=w, dtype=code, dy_coff=8, in_coff=16)
-            torch.cuda.synchronize()
-            return dw, dwa[:, 0, :cin]
-        finally:
-            L.lib().pssr_set_option(b"WGRAD_DMA", old)
-    dw1, at1 = run(1)
-    dw0, at0 = run(0)
-    tol = 2e-2
-    np.testing.assert_allclose(dw1.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * ref.abs().max().item())
-    np.testing.assert_allclose(at1.cpu().numpy(), ref[:, :, 0, 0].numpy(), rtol=tol, atol=tol * ref.abs().max().item())
-    # same products, f32 accumulation in another order (32-pixel stages vs 128-pixel tiles, other partial-slab cuts)
-    np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-3, atol=1e-4 * ref.abs().max().item())
-    np.testing.assert_allclose(at1.cpu().numpy(), at0.cpu().numpy(), rtol=1e-3, atol=1e-4 * ref.abs().max().item())
-
-
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_bn_relu_apply_equals_the_loader_prologue(dt):
     """pssr_bn_relu_apply writes relu(scale * y + shift) exactly as the convolution loaders' BatchNorm+ReLU prologue stages it: the
