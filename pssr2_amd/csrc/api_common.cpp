@@ -41,7 +41,6 @@ const Entry kEntries[] = {
     {"DWCONV_TILE", &PssrTunables::dwconv_tile, 1, 0, 1},
     {"DWWG_BLOCKS", &PssrTunables::dwwg_blocks, 1024, 1, 1 << 20},
     {"LN_BWD_BLOCKS", &PssrTunables::ln_bwd_blocks, 256, 1, 1 << 20},
-    {"HEAD_LINE_ORDER", &PssrTunables::head_line_order, 1, 0, 1},
     {"LN_DBG", &PssrTunables::ln_dbg, 0, 0, 3},
 };
 PssrTunables g_tun;

@@ -12,7 +12,6 @@
 // d(out)/d(x*scale+shift) taken straight from the f32 NCHW tensor autograd hands over.  16-bit storage (bf16 / fp16) only:
 // the exact-f32 parity build keeps the generic kernels.
 #include "common.h"
-#include "tunables.h"
 
 namespace {
 
@@ -114,78 +113,6 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const v8 a = okv[j] ? av[j][ks] : zero_frag<H>();
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = HV<H>::mma(a, bw[ks][nt], acc[nt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Z[(g * 16 + (lane >> 4) * 4 + r) * ZS + nt * 16 + (lane & 15)] = acc[nt][r];
-    }
-    __syncthreads();
-    const int ty = tid / TS, tx = tid % TS;
-    const int gy = ty0 + ty, gx = tx0 + tx;
-    if (gy < p.H && gx < p.W) {
-        for (int co = 0; co < p.cout; ++co) {
-            float s = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) s += Z[((ty + tap / 3) * HS + tx + tap % 3) * ZS + co * 9 + tap];
-            p.out[(((long)img * p.cout + co) * p.H + gy) * p.W + gx] = fmaf(s, p.out_scale, p.out_shift);
-        }
-    }
-}
-
-// The same kernel for cin = 64 with the activation stream fetched in LINE order (round 4).  The MFMA A operand wants lane l to hold
-// pixel l & 15, channels 8 (l >> 4) ..: fetched that way, the four lanes that share a pixel's 128-byte line are 16 lanes apart and every
-// wave instruction touches 16 lines for 64 bytes each -- 64 separate 16-byte requests; the kernel above moved 3.7-3.9 TB/s where the
-// element-wise kernels (adjacent lanes on adjacent 16 bytes) move 5.9.  Here lane l fetches piece l & 7 of pixel l >> 3 (8 adjacent
-// lanes = one whole line), the wave re-orders a group of 16 pixels through a private 2.5 KB LDS strip (rows 160 bytes apart: both the
-// 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups fall on distinct banks) and reads the fragments back.  No barrier: the
-// strip is the wave's own and LDS operations of one wave execute in order.
-template <typename H, int NT>
-__global__ __launch_bounds__(256) void head_fwd64_kernel(const HeadArgs p) {
-    typedef typename HV<H>::v8 v8;
-    constexpr int KS = 2, ZS = NT * 16 + 1, ST = 160;
-    __shared__ float Z[HGROUPS * 16 * ZS];
-    __shared__ __attribute__((aligned(16))) char strip[4][16 * ST];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int t = blockIdx.x;
-    const int tx0 = (t % p.tiles_x) * TS; t /= p.tiles_x;
-    const int ty0 = (t % p.tiles_y) * TS;
-    const int img = t / p.tiles_y;
-    v8 bw[KS][NT];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bw[ks][nt] = wfrag_fwd<H>(p, ks, nt, lane);
-    constexpr int GPW = (HGROUPS + 3) / 4;
-    u32x4 raw[GPW][2];
-    bool okv[GPW][2];
-    const int pl = lane >> 3, pc = lane & 7;
-#pragma unroll
-    for (int j = 0; j < GPW; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int hp = (wave + 4 * j) * 16 + pl + 8 * i;
-            const int gy = ty0 + hp / HS - 1, gx = tx0 + hp % HS - 1;
-            okv[j][i] = hp < HPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const H* src = (const H*)p.P + pix_index(img, okv[j][i] ? gy : 0, okv[j][i] ? gx : 0, p.H, p.W, p.blk) * p.p_cs + p.p_co + 8 * pc;
-            raw[j][i] = *(const u32x4*)src;
-        }
-    char* const mine = strip[wave];
-#pragma unroll
-    for (int j = 0; j < GPW; ++j) {
-        const int g = wave + 4 * j;
-        if (g >= HGROUPS) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *(u32x4*)(mine + (pl + 8 * i) * ST + pc * 16) = okv[j][i] ? raw[j][i] : u32x4{0u, 0u, 0u, 0u};
-        f32x4_t acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const v8 a = *(const v8*)(mine + (lane & 15) * ST + (ks * 4 + (lane >> 4)) * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = HV<H>::mma(a, bw[ks][nt], acc[nt]);
         }
@@ -695,17 +622,6 @@ int pssr_head_conv_fwd(const void* in, int in_cs, int in_co, int in_blk, const f
         if (dtype == PSSR_BF16) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, NT_, KS_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a); \
         else hipLaunchKernelGGL((head_fwd_kernel<f16_t, NT_, KS_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a); \
     } while (0)
-    if (ks == 2 && pssr_tunables().head_line_order) {           // cin = 64: the line-order fetch
-        if (nt == 1) {
-            if (dtype == PSSR_BF16) hipLaunchKernelGGL((head_fwd64_kernel<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-            else hipLaunchKernelGGL((head_fwd64_kernel<f16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-        } else {
-            if (dtype == PSSR_BF16) hipLaunchKernelGGL((head_fwd64_kernel<bf16_t, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-            else hipLaunchKernelGGL((head_fwd64_kernel<f16_t, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-        }
-        PSSR_LAUNCH_CHECK();
-        return PSSR_OK;
-    }
     if (nt == 1) { if (ks == 1) HF(1, 1); else if (ks == 2) HF(1, 2); else if (ks == 3) HF(1, 3); else HF(1, 4); }
     else { if (ks == 1) HF(2, 1); else if (ks == 2) HF(2, 2); else if (ks == 3) HF(2, 3); else HF(2, 4); }
 #undef HF

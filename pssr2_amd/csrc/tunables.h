@@ -20,7 +20,6 @@ struct PssrTunables {
     int dwconv_tile;        // LDS-tiled depthwise 7x7
     int dwwg_blocks;        // slabs of the depthwise weight gradient
     int ln_bwd_blocks;      // most workgroups of a LayerNorm2d backward launch (each ends with 2c f64 atomic pairs: 512 -> 256 = -5..-10 us on the 64^2 / 32^2 maps)
-    int head_line_order;    // Reconstruction.conv kernels for 64 hidden channels fetch the activation stream in line order and transpose through LDS
     int ln_dbg;             // diagnostic bits of the LayerNorm2d backward kernel (0 in production)
 };
 PssrTunables& pssr_tunables();

@@ -840,7 +840,8 @@ class Engine:
             st_in = p.bn_in
             st_in.bstats.zero_()                        # (the end of the pass adds the first encoder block's share: no zeroing there)
             if getattr(bw, "pre_border", None) is None:
-                bw.pre_border = torch.empty(8, cpre_n, dtype=torch.float32, device=dev)
+                slices = max(1, min(16, n * max(h, w) // 256))          # ~8 groups of 32 border pixels per workgroup
+                bw.pre_border = torch.empty(slices, 8, cpre_n, dtype=torch.float32, device=dev)
             ops.border_sums_nhwc(bw.dpre, n, h, w, cpre_n, bw.pre_border, code)
             norm = self.model.norm
             bw.pre_bias_sums = gpb_sums
