@@ -90,6 +90,11 @@ enum {
     PSSR_EPI_TAIL = 1,       /* out = relu(acc + bias + aux*aux_scale + aux_shift)  (ResBlock tail, _blocks.py:40) */
     PSSR_EPI_DGRAD_MASK = 2, /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
     PSSR_EPI_DGRAD_GELU = 4, /* out = acc * gelu'(aux)   (GELU backward; with FLAG_STATS stats[0..cout) += sum out)  */
+    PSSR_EPI_HEADQ = 5,      /* inference form of Reconstruction (_blocks.py:15-18) for 64 hidden channels and ONE output channel: the
+                              * epilogue of `pre` (FLAG_RELU implied, channels sub-pixel major, cout = r*r*64) does not store its
+                              * activation but the nine per-tap dot products of relu(acc + bias) with Reconstruction.conv's weights,
+                              * head_qa[pixel][sub][0..7], head_q8[pixel][sub] (f32); pssr_head_q_gather sums the nine shifted taps.
+                              * 16-bit storage, the conv_v3 tiles (h, w >= 16); PSSR_ERR_UNSUPPORTED otherwise */
     PSSR_EPI_FINAL = 3       /* out_f32_nchw = (acc + bias)*out_scale + out_shift; any cout <= 32
                                 (Reconstruction.conv + "x*128+128", _blocks.py:17, resunet.py:95)  */
 };
@@ -137,6 +142,9 @@ typedef struct pssr_conv_desc {
     /* optional scratch for split-K (layers whose tiles do not fill the chip): pssr_conv2d_workspace_bytes(desc) bytes,
      * uninitialised, caller-owned; NULL (or too small) simply disables the split                                   */
     void* workspace; int64_t workspace_bytes;
+    /* EPI_HEADQ only (appended in ABI version 3; other epilogues never read them): Reconstruction.conv's weight [1][64][3][3] f32 and
+     * the tap-product outputs [n*h*w][cout/64][8] and [n*h*w][cout/64] f32 */
+    const float* head_w; float* head_qa; float* head_q8;
 } pssr_conv_desc;
 
 int pssr_conv2d(const pssr_conv_desc* desc, pssr_stream_t stream);
@@ -223,8 +231,7 @@ int pssr_input_im2col(const float* x_nchw, void* xcol, int n, int c, int h, int 
 /* d(norm.weight), d(norm.bias) of the input BatchNorm (resunet.py:50,67) without the 16-channel data gradient of Reconstruction.pre's
  * input-channel source: by linearity the two sums follow from that source's WEIGHT gradient, pre's bias-gradient sums and the sums of
  * d(pre) over the image borders (the pixels whose taps fall into the zero padding).
- *   pssr_border_sums_nhwc: out[slices][8][c] f32 = per-channel sums (folded over the slices, in order, into border_sums[8][c] by
- *     pssr_input_norm_pre_stats) over top row / bottom row / left column / right column / the 4 corners of
+ *   pssr_border_sums_nhwc: out[slices][8][c] f32 = per-channel sums (pssr_input_norm_pre_stats adds the slices in order) over top row / bottom row / left column / right column / the 4 corners of
  *     every image of an NHWC tensor (16-bit storage), fixed summation order;
  *   pssr_input_norm_pre_stats: stats[sum g | sum g*xhat] += the contribution of weight columns [ci_begin, ci_begin + cin) of
  *     `weight` [cout][cin_w][3][3] (gradient `dweight`, same shape), bias_sums / border_sums in pre's stored channel order
@@ -232,7 +239,7 @@ int pssr_input_im2col(const float* x_nchw, void* xcol, int n, int c, int h, int 
 int pssr_border_sums_nhwc(const void* x, int cs, int co, int n, int h, int w, int c, float* out, int slices, int dtype,
                           pssr_stream_t stream);      /* out[slices][8][c]: slice z sums every slices-th group of 32 border pixels */
 int pssr_input_norm_pre_stats(const float* weight, const float* dweight, int cout, int cin_w, int ci_begin, int cin, int h0, int r2,
-                              const float* bias_sums, const float* border_slices, int slices, float* border_sums,
+                              const float* bias_sums, const float* border_slices, int slices,
                               const float* gamma, const float* beta, double* stats, pssr_stream_t stream);
 
 /* backward of the above for the parameters of ResUNet.norm: folds d(xcol) (two optional sources)
@@ -526,6 +533,13 @@ int pssr_scale_nc(const void* t, int t_cs, int t_co, const float* gate, const fl
 int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float* gamma, const float* s_mean,
                  const float* w_fc, int n, int c, int hw, float* du, float* dgamma, float* db_fc, float* dw_fc, float* add,
                  pssr_stream_t stream);
+
+/* Second half of the inference form (PSSR_EPI_HEADQ): out_f32_nchw[n][0][Y][X] = (bias + sum over the 9 taps of the tap product of
+ * the high-resolution pixel (Y, X) + tap offset, zero outside the image) * out_scale + out_shift, with the high-resolution pixel
+ * (r y + i, r x + j) stored as sub-pixel i r + j of low-resolution pixel (y, x)  (F.pixel_shuffle + Reconstruction.conv, _blocks.py:17;
+ * "x * 128 + 128", resunet.py:94).  r = 4. */
+int pssr_head_q_gather(const float* qa, const float* q8, const float* bias, float* out_nchw, int n, int h, int w, int r,
+                       float out_scale, float out_shift, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reconstruction.conv (pssr/models/_blocks.py:11,17 + "x*128+128", pssr/models/resunet.py:95) for C_out = 1..3: dedicated

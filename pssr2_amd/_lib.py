@@ -14,7 +14,7 @@ _lib = None
 
 F32, BF16, F16 = 0, 1, 2
 PRO_NONE, PRO_BN_RELU, PRO_GELU = 0, 1, 2
-EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
+EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL, EPI_DGRAD_GELU, EPI_HEADQ = 0, 1, 2, 3, 4, 5
 FLAG_RELU, FLAG_STATS = 1, 2
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("in0_blk", C.c_int32), ("out_blk", C.c_int32), ("aux_blk", C.c_int32),
         ("out_scale", C.c_float), ("out_shift", C.c_float),
         ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
+        ("head_w", c_void_p), ("head_qa", c_void_p), ("head_q8", c_void_p),
     ]
 
 

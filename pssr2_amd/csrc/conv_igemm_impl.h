@@ -365,6 +365,66 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     }
 }
 
+// PSSR_EPI_HEADQ (round 4): the inference form of Reconstruction.  In eval mode nothing needs `pre`'s 64-channel high-resolution
+// activation again, so instead of writing it (1.07 GB at batch 32) for the head kernel to read back, the epilogue multiplies it with
+// Reconstruction.conv's weights right out of the accumulators.  TR layout (conv_v3.h): a lane holds, for pixel lane & 31 of row tile mi,
+// channels (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of each 32-channel tile nj -- which IS the B-operand layout of v_mfma_f32_32x32x16 for
+// the k slots 8 (lane >> 5) + i when element e = 8 ks + i of tile nj is taken as slot i of k-step (nj, ks).  So relu(acc + bias) is
+// rounded to the storage type (exactly the value the store would have written), packed in place, and four MFMAs per row tile against
+// the head weights arranged in the matching slot order (A operand: row = tap) leave q[tap][pixel] = sum over the wave's 64 channels
+// = one sub-pixel: rows 0-3 and 8 with lanes 0-31, rows 4-7 with lanes 32-63.  36 bytes per high-resolution pixel leave instead of 128.
+template <typename T, class C>
+__device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], int tid, int x0, int y0, int img0, int n0) {
+    using X = TT<T>;
+    static_assert(sizeof(T) == 2 && C::NJ == 2 && C::MI == 4, "conv_v3 tiles of 128 channels");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int h = lane >> 5, r = lane & 31;
+    const int cbase = n0 + wn * 64;                  // first stored channel of this wave's 64 = sub * 64
+    const int sub = cbase >> 6, nsub = p.cout >> 6;
+    float bias[2][16];
+    u32x4 wa[2][2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias[nj][e] = p.bias ? p.bias[cbase + nj * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 8 * ks + i;
+                const int c = nj * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;              // hidden channel of k slot (h, i)
+                wv[i] = r < 9 ? p.head_w[c * 9 + r] : 0.f;
+            }
+            wa[nj][ks] = X::pack(wv);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        f32x16 q;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q[e] = 0.f;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(acc[mi][nj][8 * ks + i] + bias[nj][8 * ks + i], 0.f);
+                X::mma(q, wa[nj][ks], X::pack(v));
+            }
+        const int m = epi_pixel<C>(wm * 32 + r, mi);
+        const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
+        const int gy = y0 + ty, gx = x0 + tx;
+        if (gy < p.H && gx < p.W) {
+            const long pix = ((long)img0 * p.H + gy) * p.W + gx;
+            *(float4*)(p.head_qa + (pix * nsub + sub) * 8 + 4 * h) = make_float4(q[0], q[1], q[2], q[3]);
+            if (h == 0) p.head_q8[pix * nsub + sub] = q[4];
+        }
+    }
+}
+
 // picks the straight-line 8-channel epilogue when the layout allows (p.epi8, set by the host), else the generic one
 // the straight-line 8-channel epilogue of p.epi (16-bit storage, p.epi8 layouts only)
 template <typename T, int BN, class C, bool TR = false>
@@ -876,7 +936,7 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
     const long blocks = (long)p.tiles_x * p.tiles_y * a.N * p.tiles_n;
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
     int ksplit = 1;
-    if (a.epi != PSSR_EPI_FINAL && blocks < 192 && a.nchunks[0] >= 8) {
+    if (a.epi != PSSR_EPI_FINAL && a.epi != PSSR_EPI_HEADQ && blocks < 192 && a.nchunks[0] >= 8) {
         ksplit = (int)((256 + blocks - 1) / blocks);
         if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
         if (ksplit > 8) ksplit = 8;
@@ -1022,12 +1082,20 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
     if (a.cout > 64) {
         // (16x32-pixel x 64-channel v3 tiles for these wider layers too -- twice the workgroups, two rounds that drift apart instead of
         // one in lockstep -- measured 49.3 vs 47.7 us on 128 -> 128 @64^2: no)
+        if constexpr (sizeof(T) == 2) {
+            if (a.epi == PSSR_EPI_HEADQ) {            // the tap-product epilogue exists in the conv_v3 tiles only (shape checked by the entry)
+                PSSR_CHECK(a.epi8 && pssr_tunables().igemm_v3, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs the conv_v3 loop");
+                return launch3_t<T, 128>(a, s);
+            }
+        }
+        PSSR_CHECK(a.epi != PSSR_EPI_HEADQ, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs 16-bit storage");
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 128>(a)) return launch3_t<T, 128>(a, s); }
         if constexpr (sizeof(T) == 2) {
             if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
         }
         return launch_geo<T, 128>(a, s);
     }
+    PSSR_CHECK(a.epi != PSSR_EPI_HEADQ, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs cout > 64");
     if (a.cout > 32) {
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 64>(a)) return launch3_t<T, 64>(a, s); }
         return launch_geo<T, 64>(a, s);

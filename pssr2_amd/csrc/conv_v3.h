@@ -404,6 +404,9 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
                     dst[((mi * C::NJ + nj) * 4 + q) * 256] = make_float4(acc[mi][nj][4 * q], acc[mi][nj][4 * q + 1], acc[mi][nj][4 * q + 2], acc[mi][nj][4 * q + 3]);
         return;
     }
+    if constexpr (BN == 128) {
+        if (p.epi == PSSR_EPI_HEADQ) { conv_headq_epilogue<T, C>(p, acc, tid, x0, y0, img0, n0); return; }
+    }
     conv_epilogue8_any<T, BN, C, true>(p, acc, smem, tid, x0, y0, img0, n0);
 #ifdef PSSR_V3_STAMPS
     if (p.stamps) {                          // second half of the buffer: [0] epilogue instructions done, [1] its stores acknowledged

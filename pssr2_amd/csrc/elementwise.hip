@@ -708,51 +708,60 @@ __global__ __launch_bounds__(TPB) void border_sums_kernel(Ref x, int n, int h, i
 //   sum g        = sum_{o,t} W1[o][t] * (sum over the pixels q with q + off_t inside of d(pre)[q][o])
 //                = sum_{o,t} W1[o][t] * (S[o] - rows/columns of the border that tap t excludes + the corner counted twice)
 //   sum g * xhat = (sum_{o,t} W1[o][t] * dW1[o][t] - beta * sum g) / gamma        (dW1 = d(pre)^T xcol is the weight gradient of that source)
-// S = bias-gradient sums of pre, borders = border_sums_kernel(d(pre)), both in pre's stored channel order n' = sub * h0 + c of weight row
-// o = c * r2 + sub.  One workgroup; f64 accumulation in a fixed order; the result is added to stripe 0 of the statistic rows.
+// S = bias-gradient sums of pre, borders = border_sums_kernel(d(pre)) (its slices added in order), both in pre's stored channel order
+// n' = sub * h0 + c of weight row o = c * r2 + sub.  Both sums are linear in the per-row terms, so a workgroup owns 64 weight rows
+// (thread = row, tap group), reduces in LDS in a fixed order and adds its share to the statistic rows with the order-independent
+// stat_add.  (A first version ran as ONE workgroup: a latency-bound chain of ~700 loads per thread that took 0.3 ms beside the
+// saturated backward pass and held the in-order weight-gradient stream up for as long.)
 __global__ __launch_bounds__(TPB) void input_norm_pre_stats_kernel(const float* __restrict__ wgt, const float* __restrict__ dwg, int cout, int cin_w, int ci0,
-                                                                   int cin, int h0, int r2, const float* __restrict__ S, const float* Bp,
-                                                                   int slices, float* B, const float* __restrict__ gamma,
-                                                                   const float* __restrict__ beta, double* stats) {
+                                                                   int cin, int h0, int r2, const float* __restrict__ S, const float* __restrict__ Bp,
+                                                                   int slices, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   double* stats) {
+    __shared__ float Bl[8][64];
     __shared__ double red[2][TPB];
-    // fold the border-sum slices (fixed order) into slice 0's place first
-    for (int i = threadIdx.x; i < 8 * cout; i += TPB) {
+    const int o0 = blockIdx.x * 64;
+    // border sums of this workgroup's 64 rows: the slices added in order
+    for (int i = threadIdx.x; i < 8 * 64; i += TPB) {
+        const int kind = i >> 6, o = o0 + (i & 63);
         float t = 0.f;
-        for (int z = 0; z < slices; ++z) t += Bp[(long)z * 8 * cout + i];
-        B[i] = t;
+        if (o < cout) {
+            const int np = (o % r2) * h0 + o / r2;
+            for (int z = 0; z < slices; ++z) t += Bp[((long)z * 8 + kind) * cout + np];
+        }
+        Bl[kind][i & 63] = t;
     }
     __syncthreads();
+    const int ol = threadIdx.x >> 2, tq = threadIdx.x & 3, o = o0 + ol;
     for (int ch = 0; ch < cin; ++ch) {
         double s1 = 0.0, a = 0.0;
-        for (int o = threadIdx.x; o < cout; o += TPB) {
-            const int np = (o % r2) * h0 + o / r2;
+        if (o < cout) {
             const float* wr = wgt + ((long)o * cin_w + ci0 + ch) * 9;
             const float* dr = dwg + ((long)o * cin_w + ci0 + ch) * 9;
-            const double s = S[np];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            const double s = S[(o % r2) * h0 + o / r2];
+            for (int t = tq; t < 9; t += 4) {
                 const int ky = t / 3, kx = t % 3;
                 double st = s;
-                if (ky == 0) st -= B[0 * cout + np];
-                if (ky == 2) st -= B[1 * cout + np];
-                if (kx == 0) st -= B[2 * cout + np];
-                if (kx == 2) st -= B[3 * cout + np];
-                if (ky != 1 && kx != 1) st += B[(4 + (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0)) * cout + np];
+                if (ky == 0) st -= Bl[0][ol];
+                if (ky == 2) st -= Bl[1][ol];
+                if (kx == 0) st -= Bl[2][ol];
+                if (kx == 2) st -= Bl[3][ol];
+                if (ky != 1 && kx != 1) st += Bl[4 + (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0)][ol];
                 s1 += (double)wr[t] * st;
                 a += (double)wr[t] * (double)dr[t];
             }
         }
         red[0][threadIdx.x] = s1; red[1][threadIdx.x] = a;
         __syncthreads();
-        for (int o = TPB / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        for (int k = TPB / 2; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
             const double g1 = red[0][0];
             const double g2 = (red[1][0] - (double)beta[ch] * g1) / (double)gamma[ch];
-            stat_add(stats + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g1);
-            stat_add(stats + cin + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g2);
+            double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * cin;
+            stat_add(st + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g1);
+            stat_add(st + cin + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g2);
         }
         __syncthreads();
     }
@@ -913,14 +922,13 @@ int pssr_border_sums_nhwc(const void* x, int cs, int co, int n, int h, int w, in
 }
 
 int pssr_input_norm_pre_stats(const float* weight, const float* dweight, int cout, int cin_w, int ci_begin, int cin, int h0, int r2,
-                              const float* bias_sums, const float* border_slices, int slices, float* border_sums, const float* gamma,
-                              const float* beta, double* stats, pssr_stream_t s) {
-    PSSR_CHECK(weight && dweight && bias_sums && border_slices && border_sums && gamma && beta && stats && slices >= 1, PSSR_ERR_ARG,
-               "input_norm_pre_stats: null pointer");
+                              const float* bias_sums, const float* border_slices, int slices, const float* gamma, const float* beta,
+                              double* stats, pssr_stream_t s) {
+    PSSR_CHECK(weight && dweight && bias_sums && border_slices && gamma && beta && stats && slices >= 1, PSSR_ERR_ARG, "input_norm_pre_stats: null pointer");
     PSSR_CHECK(cout > 0 && cin > 0 && ci_begin >= 0 && ci_begin + cin <= cin_w && h0 > 0 && r2 > 0 && cout == h0 * r2, PSSR_ERR_ARG,
                "input_norm_pre_stats: shape (cout %d, cin %d+%d of %d, h0 %d, r2 %d)", cout, ci_begin, cin, cin_w, h0, r2);
-    hipLaunchKernelGGL(input_norm_pre_stats_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)s, weight, dweight, cout, cin_w, ci_begin, cin, h0, r2,
-                       bias_sums, border_slices, slices, border_sums, gamma, beta, stats);
+    hipLaunchKernelGGL(input_norm_pre_stats_kernel, dim3((cout + 63) / 64), dim3(TPB), 0, (hipStream_t)s, weight, dweight, cout, cin_w, ci_begin, cin, h0, r2,
+                       bias_sums, border_slices, slices, gamma, beta, stats);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

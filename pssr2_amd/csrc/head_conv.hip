@@ -134,6 +134,58 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ inference: gather of the tap products
+// Second half of PSSR_EPI_HEADQ (conv_igemm_impl.h: conv_headq_epilogue): qa[lrpix][sub][0..7], q8[lrpix][sub] hold, for the
+// high-resolution pixel (r y + i, r x + j) = (low-resolution pixel (y, x), sub-pixel i r + j), its nine products with
+// Reconstruction.conv's taps; out[p] = bias + sum_tap q[tap][p + off(tap)] (zero outside the image).  Every product is used exactly
+// once, so the kernel is one coalesced read of both arrays: a workgroup stages the products of an 8 x 8 block of low-resolution pixels
+// plus a ring of one (10 x 10 x 16 x 9 floats = 57.6 KB) and each thread sums 4 adjacent outputs of one high-resolution row.
+template <int R>
+__global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restrict__ qa, const float* __restrict__ q8, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int n, int h, int w, float out_scale, float out_shift) {
+    constexpr int R2 = R * R, TB = 8, HB = TB + 2, NV = 9;
+    static_assert(R == 4, "4 x upscaling: 4 outputs of a row per thread");
+    extern __shared__ __attribute__((aligned(16))) float Lq[];       // [HB * HB][R2][NV]
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x * TB, by = blockIdx.y * TB, img = blockIdx.z;
+    // stage: (halo pixel, sub) pairs, 8 + 1 floats each; float4 pieces of qa
+    for (int i = tid; i < HB * HB * R2 * 2; i += 256) {
+        const int part = i & 1, ps = i >> 1;                // float4 part 0 / 1 of the 8 first taps
+        const int sub = ps % R2, hp = ps / R2;
+        const int ly = by + hp / HB - 1, lx = bx + hp % HB - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ly >= 0 && ly < h && lx >= 0 && lx < w)
+            v = *(const float4*)(qa + ((((long)img * h + ly) * w + lx) * R2 + sub) * 8 + 4 * part);
+        float* d = Lq + (hp * R2 + sub) * NV + 4 * part;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = tid; i < HB * HB * R2; i += 256) {
+        const int sub = i % R2, hp = i / R2;
+        const int ly = by + hp / HB - 1, lx = bx + hp % HB - 1;
+        float v = 0.f;
+        if (ly >= 0 && ly < h && lx >= 0 && lx < w) v = q8[(((long)img * h + ly) * w + lx) * R2 + sub];
+        Lq[(hp * R2 + sub) * NV + 8] = v;
+    }
+    __syncthreads();
+    const float b = bias ? bias[0] : 0.f;
+    // thread -> high-resolution row yl (0 .. 8 R - 1) of the block, low-resolution column xb: 4 outputs
+    const int yl = tid >> 3, xb = tid & 7;
+    const int Y = by * R + yl, X0 = (bx + xb) * R;
+    if (by + yl / R >= h || bx + xb >= w) return;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = b;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yh = yl + R + tap / 3 - 1, xh = xb * R + j + R + tap % 3 - 1;       // position in the staged block (ring of one pixel = R rows / columns)
+            s += Lq[(((yh / R) * HB + xh / R) * R2 + (yh % R) * R + xh % R) * NV + tap];
+        }
+        o[j] = fmaf(s, out_scale, out_shift);
+    }
+    *(float4*)(out + ((long)img * h * R + Y) * ((long)w * R) + X0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------------------------------------ dgrad (+ ReLU mask)
 template <typename H, int NT>     // NT = cin/16 output-channel tiles; cout*9 <= 32 (one K step)
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadArgs p) {
@@ -625,6 +677,23 @@ int pssr_head_conv_fwd(const void* in, int in_cs, int in_co, int in_blk, const f
     if (nt == 1) { if (ks == 1) HF(1, 1); else if (ks == 2) HF(1, 2); else if (ks == 3) HF(1, 3); else HF(1, 4); }
     else { if (ks == 1) HF(2, 1); else if (ks == 2) HF(2, 2); else if (ks == 3) HF(2, 3); else HF(2, 4); }
 #undef HF
+    PSSR_LAUNCH_CHECK();
+    return PSSR_OK;
+}
+
+int pssr_head_q_gather(const float* qa, const float* q8, const float* bias, float* out_nchw, int n, int h, int w, int r, float out_scale,
+                       float out_shift, pssr_stream_t s) {
+    PSSR_CHECK(qa && q8 && out_nchw && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "head_q_gather: bad args");
+    PSSR_CHECK(r == 4, PSSR_ERR_UNSUPPORTED, "head_q_gather: r=%d (4 x upscaling only)", r);
+    PSSR_CHECK(n <= 65535 && (h + 7) / 8 <= 65535, PSSR_ERR_ARG, "head_q_gather: grid");
+    constexpr int LDS = 10 * 10 * 16 * 9 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)head_q_gather_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head_q_gather_kernel<4>, dim3((w + 7) / 8, (h + 7) / 8, n), dim3(256), LDS, (hipStream_t)s, qa, q8, bias, out_nchw, n, h, w,
+                       out_scale, out_shift);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

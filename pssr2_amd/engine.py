@@ -42,6 +42,7 @@ _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 _FUSE_DOUT = __import__("os").environ.get("PSSR_FUSE_DOUT", "1") != "0"
 _OVERWRITE_GRADS = __import__("os").environ.get("PSSR_OVERWRITE_GRADS", "1") != "0"
 _XCOL_LINEAR = __import__("os").environ.get("PSSR_XCOL_LINEAR", "1") != "0"
+_HEAD_FUSE = __import__("os").environ.get("PSSR_HEAD_FUSE", "1") != "0"      # eval mode: Reconstruction.conv inside pre's epilogue (EPI_HEADQ)
 _ABL = frozenset(x for x in __import__("os").environ.get("PSSR_ABLATE", "").split(",") if x)
 
 class _Arena:
@@ -740,15 +741,17 @@ class Engine:
             from . import atrous as A
             A.psp_forward(self, p.rpool, m.reconstruction_pool, feat, 0, n, code, p.rpool_out, 0, train)
             feat = p.rpool_out
-        out = self._head_forward(p, feat, x)
+        out = self._head_forward(p, feat, x, train)
         self._flush_fwd()
         self.saved = (p, x) if train else None
         return out
 
     # ------------------------------------------------------------------ reconstruction head (shared with RDEngine)
-    def _head_forward(self, p, feat, x):
+    def _head_forward(self, p, feat, x, train=True):
         """relu(conv3x3([feat | x0])) in sub-pixel-major channel order (== pixel-shuffled, blocked layout) -> conv3x3 ->
-        x*128+128 (pssr/models/_blocks.py:15-18, pssr/models/resunet.py:90-95)."""
+        x*128+128 (pssr/models/_blocks.py:15-18, pssr/models/resunet.py:90-95).  Eval mode (nothing is kept for a backward pass):
+        `pre`'s epilogue multiplies its activation with the final convolution's taps in registers and a gather kernel sums the nine
+        shifted products -- the 64-channel high-resolution tensor (1.07 GB at batch 32) is neither written nor read."""
         rec = self.model.reconstruction
         n, h, w, code, h0, r = p.n, p.h, p.w, p.code, self.h0, self.r
         cpre = self._conv(rec.pre,
@@ -757,9 +760,18 @@ class Engine:
                           dgrad0=dict(mode=1, ci_begin=0, ci_count=h0, n_perm=self.pre_perm),
                           dgrad1=dict(mode=3, ci_begin=h0, ci_count=self.cin, n_perm=self.pre_perm))
         p.pre_bias = rec.pre.bias.detach()[self.pre_perm_long].contiguous()
+        out = torch.empty(n, self.cout, h * r, w * r, dtype=torch.float32, device=x.device)
+        if not train and _HEAD_FUSE and ops.head_q_supported(code, h0, self.cout, r, h, w):
+            if getattr(p, "head_qa", None) is None:
+                p.head_qa = torch.empty(n, h, w, r * r, 8, dtype=torch.float32, device=x.device)
+                p.head_q8 = torch.empty(n, h, w, r * r, dtype=torch.float32, device=x.device)
+            ops.conv2d(feat, h0, cpre.get("fwd0", code), p.head_qa, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias,
+                       x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), epilogue=L.EPI_HEADQ,
+                       head_w=rec.conv.weight, head_qa=p.head_qa, head_q8=p.head_q8)
+            ops.head_q_gather(p.head_qa, p.head_q8, rec.conv.bias, out, n, h, w, r, 128.0, 128.0)
+            return out
         ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias,
                    x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)
-        out = torch.empty(n, self.cout, h * r, w * r, dtype=torch.float32, device=x.device)
         pre_hr = p.pre.view(n, h * r, w * r, h0)
         if ops.head_conv_supported(code, h0, self.cout):
             ops.head_conv_fwd(pre_hr, self.blk, rec.conv.weight, rec.conv.bias, out, n, h * r, w * r, h0, self.cout, 128.0, 128.0, code)

@@ -59,8 +59,9 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
            x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
            pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
            aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None,
-           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False):
-    """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff)."""
+           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False, head_w=None, head_qa=None, head_q8=None):
+    """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff).  EPI_HEADQ: ``out`` is unused (pass
+    ``head_qa``), the tap products go to ``head_qa`` / ``head_q8``."""
     d = L.ConvDesc()
     d.dtype = w0.dtype
     d.n, d.h, d.w = n, h, w
@@ -80,6 +81,9 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
     d.in0_blk, d.out_blk, d.aux_blk, d.out_scale, d.out_shift = in0_blk, out_blk, aux_blk, out_scale, out_shift
     if epilogue == L.EPI_FINAL:      # f32 NCHW output [n, cout, h, w]
         d.out_cstride, d.out_coff = cout, 0
+    if epilogue == L.EPI_HEADQ:
+        d.out_cstride, d.out_coff = cout, 0
+        d.head_w, d.head_qa, d.head_q8 = L.ptr(head_w), L.ptr(head_qa), L.ptr(head_q8)
     ws_bytes = L.lib().pssr_conv2d_workspace_bytes(C.byref(d))      # > 0: the library wants to split K (under-filled grid)
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device)
@@ -197,7 +201,7 @@ def input_norm_pre_stats(weight, dweight, h0, cin, r2, bias_sums, border_sums, g
     gradient ``dweight`` (same shape as ``weight`` [r2 * h0, h0 + cin, 3, 3]), pre's bias sums and d(pre)'s border sums."""
     cout, cin_w = weight.shape[0], weight.shape[1]
     L.check(L.lib().pssr_input_norm_pre_stats(L.ptr(weight), L.ptr(dweight), cout, cin_w, h0, cin, h0, r2, L.ptr(bias_sums), L.ptr(border_sums),
-                                              border_sums.shape[0], L.ptr(border_sums), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.stream_ptr()),
+                                              border_sums.shape[0], L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.stream_ptr()),
             "pssr_input_norm_pre_stats")
 
 
@@ -541,6 +545,16 @@ def head_conv_bwd(g, g_scale, weight, act, dact, blk, dw, bias_sum, n, h, w, cin
     """dgrad + wgrad (+ the bias sums of the pixel-shuffle conv in front) in one pass over the activation."""
     L.check(L.lib().pssr_head_conv_bwd(L.ptr(g), C.c_float(g_scale), L.ptr(weight), L.ptr(act), act.shape[-1], 0, L.ptr(dact), dact.shape[-1], 0,
                                        blk, L.ptr(dw), L.ptr(bias_sum), n, h, w, cin, cout, dtype, L.stream_ptr()), "pssr_head_conv_bwd")
+
+
+def head_q_supported(dtype, h0, cout, r, h, w):
+    """The inference form of Reconstruction (EPI_HEADQ + head_q_gather): 16-bit storage, 64 hidden channels, one output channel, 4x."""
+    return dtype != L.F32 and h0 == 64 and cout == 1 and r == 4 and h >= 16 and w >= 16 and L.lib().pssr_get_option(b"IGEMM_V3") > 0
+
+
+def head_q_gather(qa, q8, bias, out, n, h, w, r, out_scale, out_shift):
+    L.check(L.lib().pssr_head_q_gather(L.ptr(qa), L.ptr(q8), L.ptr(bias), L.ptr(out), n, h, w, r, C.c_float(out_scale), C.c_float(out_shift),
+                                       L.stream_ptr()), "pssr_head_q_gather")
 
 
 def head_conv_bwd_rows(g, g_scale, weight, act, dact, blk, dw_rows, bias_rows, n, h, w, cin, cout, dtype):

@@ -445,7 +445,7 @@ class RDEngine(Engine):
         if p.rpool is not None:
             A.psp_forward(self, p.rpool, m.reconstruction_pool, p.feat, 0, n, code, p.rpool_out, 0, train)
             feat = p.rpool_out
-        out = self._head_forward(p, feat, x)
+        out = self._head_forward(p, feat, x, train)
         self._flush_fwd()
         self.saved = (p, x) if train else None
         return out

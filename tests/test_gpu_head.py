@@ -63,3 +63,35 @@ def test_head_conv(case, dt):
         if bsum is not None:
             want_b = da.float().cpu().reshape(n, h // r, w // r, r * r * cin).sum(dim=(0, 1, 2))
             np.testing.assert_allclose(bsum.cpu().numpy(), want_b.numpy(), rtol=1e-3, atol=1e-3 * want_b.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 36, 52), (3, 16, 16)])
+def test_inference_head_inside_pre_epilogue(monkeypatch, dt, shape):
+    """Round 4: in eval mode Reconstruction.pre's epilogue forms the nine tap products of Reconstruction.conv out of its accumulators
+    (PSSR_EPI_HEADQ) and pssr_head_q_gather sums the shifted taps -- the pixel-shuffled 64-channel tensor is never stored.  Against the
+    stored-activation path (PSSR_HEAD_FUSE=0) on the same weights: the same 16-bit products, f32 sums in another order."""
+    import pssr2_amd.engine as E
+    from pssr2_amd.models import ResUNet
+    n, h, w = shape
+    torch.manual_seed(h + w)
+    model = ResUNet(hidden=[64, 128], depth=1).cuda().eval()
+    model.infer_dtype = dt
+    with torch.no_grad():
+        model.reconstruction.pre.bias.normal_(0, 0.2)
+        model.reconstruction.conv.weight.mul_(3.0)
+        model.reconstruction.conv.bias.fill_(0.1)
+    x = (torch.rand(n, 1, h, w) * 255).cuda()
+    outs = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(E, "_HEAD_FUSE", fuse)
+        with torch.no_grad():
+            outs[fuse] = model(x).float().clone()
+        plan = list(model._engine.plans.values())[-1]
+        assert (getattr(plan, "head_qa", None) is not None) == fuse or not fuse
+    a, b = outs[True], outs[False]
+    assert a.shape == (n, 1, 4 * h, 4 * w) and torch.isfinite(a).all()
+    err = float((a - b).abs().max())
+    assert err <= 2e-3 * max(1.0, float(b.abs().max()) / 128), err
+    ua, ub = a.clamp(0, 255).to(torch.uint8), b.clamp(0, 255).to(torch.uint8)
+    assert float((ua != ub).float().mean()) <= 1e-3 and int((ua.int() - ub.int()).abs().max()) <= 1
