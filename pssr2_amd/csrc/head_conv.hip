@@ -139,51 +139,54 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
 // high-resolution pixel (r y + i, r x + j) = (low-resolution pixel (y, x), sub-pixel i r + j), its nine products with
 // Reconstruction.conv's taps; out[p] = bias + sum_tap q[tap][p + off(tap)] (zero outside the image).  Every product is used exactly
 // once, so the kernel is one coalesced read of both arrays: a workgroup stages the products of an 8 x 8 block of low-resolution pixels
-// plus a ring of one (10 x 10 x 16 x 9 floats = 57.6 KB) and each thread sums 4 adjacent outputs of one high-resolution row.
+// plus a ring of one as nine high-resolution tap planes (59 KB) and each thread sums 4 outputs of one high-resolution column.
 template <int R>
 __global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restrict__ qa, const float* __restrict__ q8, const float* __restrict__ bias,
                                                             float* __restrict__ out, int n, int h, int w, float out_scale, float out_shift) {
-    constexpr int R2 = R * R, TB = 8, HB = TB + 2, NV = 9;
-    static_assert(R == 4, "4 x upscaling: 4 outputs of a row per thread");
-    extern __shared__ __attribute__((aligned(16))) float Lq[];       // [HB * HB][R2][NV]
+    constexpr int R2 = R * R, TB = 8, HB = TB + 2, HR = HB * R, PITCH = HR + 1, PLANE = HR * PITCH + 1;
+    static_assert(R == 4, "4 x upscaling");
+    // nine tap planes of the (8 + 2) x 4 = 40 x 40 high-resolution block, rows 41 floats apart: in the sum below the 32 lanes of a read
+    // group walk 32 consecutive floats of one row (conflict-free); the staging stores of a lane pair (taps 0-3 / 4-7 of one pixel) go to
+    // planes 4 * PLANE floats = 4 banks apart
+    extern __shared__ __attribute__((aligned(16))) float Lq[];       // [9][PLANE]
     const int tid = threadIdx.x;
     const int bx = blockIdx.x * TB, by = blockIdx.y * TB, img = blockIdx.z;
-    // stage: (halo pixel, sub) pairs, 8 + 1 floats each; float4 pieces of qa
     for (int i = tid; i < HB * HB * R2 * 2; i += 256) {
-        const int part = i & 1, ps = i >> 1;                // float4 part 0 / 1 of the 8 first taps
+        const int part = i & 1, ps = i >> 1;                // float4 part 0 / 1 of the 8 first taps of (halo pixel, sub-pixel) ps
         const int sub = ps % R2, hp = ps / R2;
-        const int ly = by + hp / HB - 1, lx = bx + hp % HB - 1;
+        const int hy = hp / HB, hx = hp % HB;
+        const int ly = by + hy - 1, lx = bx + hx - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ly >= 0 && ly < h && lx >= 0 && lx < w)
             v = *(const float4*)(qa + ((((long)img * h + ly) * w + lx) * R2 + sub) * 8 + 4 * part);
-        float* d = Lq + (hp * R2 + sub) * NV + 4 * part;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        float* d = Lq + (4 * part) * PLANE + (hy * R + sub / R) * PITCH + hx * R + sub % R;
+        d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
     }
     for (int i = tid; i < HB * HB * R2; i += 256) {
         const int sub = i % R2, hp = i / R2;
-        const int ly = by + hp / HB - 1, lx = bx + hp % HB - 1;
+        const int hy = hp / HB, hx = hp % HB;
+        const int ly = by + hy - 1, lx = bx + hx - 1;
         float v = 0.f;
         if (ly >= 0 && ly < h && lx >= 0 && lx < w) v = q8[(((long)img * h + ly) * w + lx) * R2 + sub];
-        Lq[(hp * R2 + sub) * NV + 8] = v;
+        Lq[8 * PLANE + (hy * R + sub / R) * PITCH + hx * R + sub % R] = v;
     }
     __syncthreads();
     const float b = bias ? bias[0] : 0.f;
-    // thread -> high-resolution row yl (0 .. 8 R - 1) of the block, low-resolution column xb: 4 outputs
-    const int yl = tid >> 3, xb = tid & 7;
-    const int Y = by * R + yl, X0 = (bx + xb) * R;
-    if (by + yl / R >= h || bx + xb >= w) return;
-    float o[4];
+    // thread -> column xl (0 .. 31) of the block's 32 x 32 outputs, rows yl = tid / 32 + 8 k
+    const int xl = tid & 31;
+    const int X = bx * R + xl;
+    if (X >= w * R) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int k = 0; k < 4; ++k) {
+        const int yl = (tid >> 5) + 8 * k;
+        const int Y = by * R + yl;
+        if (Y >= h * R) continue;
         float s = b;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yh = yl + R + tap / 3 - 1, xh = xb * R + j + R + tap % 3 - 1;       // position in the staged block (ring of one pixel = R rows / columns)
-            s += Lq[(((yh / R) * HB + xh / R) * R2 + (yh % R) * R + xh % R) * NV + tap];
-        }
-        o[j] = fmaf(s, out_scale, out_shift);
+        for (int tap = 0; tap < 9; ++tap)
+            s += Lq[tap * PLANE + (yl + R + tap / 3 - 1) * PITCH + xl + R + tap % 3 - 1];
+        out[((long)img * h * R + Y) * ((long)w * R) + X] = fmaf(s, out_scale, out_shift);
     }
-    *(float4*)(out + ((long)img * h * R + Y) * ((long)w * R) + X0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ dgrad (+ ReLU mask)
@@ -686,7 +689,7 @@ int pssr_head_q_gather(const float* qa, const float* q8, const float* bias, floa
     PSSR_CHECK(qa && q8 && out_nchw && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "head_q_gather: bad args");
     PSSR_CHECK(r == 4, PSSR_ERR_UNSUPPORTED, "head_q_gather: r=%d (4 x upscaling only)", r);
     PSSR_CHECK(n <= 65535 && (h + 7) / 8 <= 65535, PSSR_ERR_ARG, "head_q_gather: grid");
-    constexpr int LDS = 10 * 10 * 16 * 9 * 4;
+    constexpr int LDS = 9 * (40 * 41 + 1) * 4;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)head_q_gather_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
