@@ -228,20 +228,6 @@ int pssr_bn_bwd_apply(const void* g, int g_cs, int g_co, const void* y, int y_cs
 int pssr_input_im2col(const float* x_nchw, void* xcol, int n, int c, int h, int w, int xc,
                       float pre_scale, float pre_shift, const float* scale, const float* shift,
                       int dtype, pssr_stream_t stream);
-/* d(norm.weight), d(norm.bias) of the input BatchNorm (resunet.py:50,67) without the 16-channel data gradient of Reconstruction.pre's
- * input-channel source: by linearity the two sums follow from that source's WEIGHT gradient, pre's bias-gradient sums and the sums of
- * d(pre) over the image borders (the pixels whose taps fall into the zero padding).
- *   pssr_border_sums_nhwc: out[slices][8][c] f32 = per-channel sums (pssr_input_norm_pre_stats adds the slices in order) over top row / bottom row / left column / right column / the 4 corners of
- *     every image of an NHWC tensor (16-bit storage), fixed summation order;
- *   pssr_input_norm_pre_stats: stats[sum g | sum g*xhat] += the contribution of weight columns [ci_begin, ci_begin + cin) of
- *     `weight` [cout][cin_w][3][3] (gradient `dweight`, same shape), bias_sums / border_sums in pre's stored channel order
- *     n' = (o % r2) * h0 + o / r2 (_blocks.py:15-17: pixel_shuffle consumes output channel o = c * r2 + sub). */
-int pssr_border_sums_nhwc(const void* x, int cs, int co, int n, int h, int w, int c, float* out, int slices, int dtype,
-                          pssr_stream_t stream);      /* out[slices][8][c]: slice z sums every slices-th group of 32 border pixels */
-int pssr_input_norm_pre_stats(const float* weight, const float* dweight, int cout, int cin_w, int ci_begin, int cin, int h0, int r2,
-                              const float* bias_sums, const float* border_slices, int slices,
-                              const float* gamma, const float* beta, double* stats, pssr_stream_t stream);
-
 /* backward of the above for the parameters of ResUNet.norm: folds d(xcol) (two optional sources)
  * onto the normalised input and accumulates stats = [sum dx0, sum dx0*xhat0] per input channel. */
 int pssr_input_norm_bwd(const void* dxcol_a, const void* dxcol_b, int xc, const float* x_nchw,

@@ -659,114 +659,6 @@ __global__ __launch_bounds__(TPB) void relu_bwd_stats8_unshuffle_kernel(Ref dhi,
     }
 }
 
-// Per-channel sums over the border pixels of every image of an NHWC tensor: out[kind][c], kind 0 = top row (y = 0), 1 = bottom row,
-// 2 = left column (x = 0), 3 = right column, 4-7 = the corners (0,0), (0,w-1), (h-1,0), (h-1,w-1).  A workgroup owns 64 channels (one
-// 128-byte line per pixel in 16-bit storage) of one kind: thread = (pixel lane t / 8, 8-channel piece t % 8), fixed summation order
-// (per-thread stride loop, then a tree over the 32 pixel lanes): bit-reproducible.  Used by the input-BatchNorm gradient below.
-template <typename T>
-__global__ __launch_bounds__(TPB) void border_sums_kernel(Ref x, int n, int h, int w, int c, float* __restrict__ out) {
-    using X = TT<T>;
-    static_assert(sizeof(T) == 2, "16-bit storage");
-    __shared__ float lds[32][8][8];
-    const int kind = blockIdx.y, c0 = blockIdx.x * 64 + (threadIdx.x & 7) * 8, pl = threadIdx.x >> 3;
-    const int len = kind < 2 ? w : kind < 4 ? h : 1;
-    // blockIdx.z owns every gridDim.z-th group of 32 border pixels and writes its own slice out[z][kind][c] (the consumer adds the
-    // slices in order): a single workgroup per (kind, channel group) walked 128 dependent-latency iterations at c2's size -- 130 us on
-    // the backward's dependent chain for 33 MB
-    out += (long)blockIdx.z * 8 * c;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c0 < c)
-#pragma unroll 4
-        for (int i = pl + 32 * blockIdx.z; i < n * len; i += 32 * gridDim.z) {
-            const int img = i / len, j = i - img * len;
-            int py, px;
-            if (kind == 0) { py = 0; px = j; } else if (kind == 1) { py = h - 1; px = j; }
-            else if (kind == 2) { py = j; px = 0; } else if (kind == 3) { py = j; px = w - 1; }
-            else { py = (kind & 2) ? h - 1 : 0; px = (kind & 1) ? w - 1 : 0; }
-            float v[8];
-            X::unpack(*(const u32x4*)at<T>(x, ((long)img * h + py) * w + px, c0), v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
-        }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) lds[pl][threadIdx.x & 7][e] = acc[e];
-    __syncthreads();
-    for (int o = 16; o > 0; o >>= 1) {
-        if (pl < o)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) lds[pl][threadIdx.x & 7][e] += lds[pl + o][threadIdx.x & 7][e];
-        __syncthreads();
-    }
-    if (pl == 0 && c0 < c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) out[(long)kind * c + c0 + e] = lds[0][threadIdx.x & 7][e];
-}
-
-// Input-BatchNorm statistics [sum g, sum g * xhat] of the part of d(xn) that arrives through Reconstruction.pre's input-channel source,
-// WITHOUT the 16-channel data gradient d(xcol) = W1^T d(pre) (a pass over the 1 GB d(pre) tensor for two scalars per channel).  With
-// xcol[q][ch*9+t] = xn[q + off_t] inside the image and 0 outside (xn = gamma * xhat + beta):
-//   sum g        = sum_{o,t} W1[o][t] * (sum over the pixels q with q + off_t inside of d(pre)[q][o])
-//                = sum_{o,t} W1[o][t] * (S[o] - rows/columns of the border that tap t excludes + the corner counted twice)
-//   sum g * xhat = (sum_{o,t} W1[o][t] * dW1[o][t] - beta * sum g) / gamma        (dW1 = d(pre)^T xcol is the weight gradient of that source)
-// S = bias-gradient sums of pre, borders = border_sums_kernel(d(pre)) (its slices added in order), both in pre's stored channel order
-// n' = sub * h0 + c of weight row o = c * r2 + sub.  Both sums are linear in the per-row terms, so a workgroup owns 64 weight rows
-// (thread = row, tap group), reduces in LDS in a fixed order and adds its share to the statistic rows with the order-independent
-// stat_add.  (A first version ran as ONE workgroup: a latency-bound chain of ~700 loads per thread that took 0.3 ms beside the
-// saturated backward pass and held the in-order weight-gradient stream up for as long.)
-__global__ __launch_bounds__(TPB) void input_norm_pre_stats_kernel(const float* __restrict__ wgt, const float* __restrict__ dwg, int cout, int cin_w, int ci0,
-                                                                   int cin, int h0, int r2, const float* __restrict__ S, const float* __restrict__ Bp,
-                                                                   int slices, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                   double* stats) {
-    __shared__ float Bl[8][64];
-    __shared__ double red[2][TPB];
-    const int o0 = blockIdx.x * 64;
-    // border sums of this workgroup's 64 rows: the slices added in order
-    for (int i = threadIdx.x; i < 8 * 64; i += TPB) {
-        const int kind = i >> 6, o = o0 + (i & 63);
-        float t = 0.f;
-        if (o < cout) {
-            const int np = (o % r2) * h0 + o / r2;
-            for (int z = 0; z < slices; ++z) t += Bp[((long)z * 8 + kind) * cout + np];
-        }
-        Bl[kind][i & 63] = t;
-    }
-    __syncthreads();
-    const int ol = threadIdx.x >> 2, tq = threadIdx.x & 3, o = o0 + ol;
-    for (int ch = 0; ch < cin; ++ch) {
-        double s1 = 0.0, a = 0.0;
-        if (o < cout) {
-            const float* wr = wgt + ((long)o * cin_w + ci0 + ch) * 9;
-            const float* dr = dwg + ((long)o * cin_w + ci0 + ch) * 9;
-            const double s = S[(o % r2) * h0 + o / r2];
-            for (int t = tq; t < 9; t += 4) {
-                const int ky = t / 3, kx = t % 3;
-                double st = s;
-                if (ky == 0) st -= Bl[0][ol];
-                if (ky == 2) st -= Bl[1][ol];
-                if (kx == 0) st -= Bl[2][ol];
-                if (kx == 2) st -= Bl[3][ol];
-                if (ky != 1 && kx != 1) st += Bl[4 + (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0)][ol];
-                s1 += (double)wr[t] * st;
-                a += (double)wr[t] * (double)dr[t];
-            }
-        }
-        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = a;
-        __syncthreads();
-        for (int k = TPB / 2; k > 0; k >>= 1) {
-            if ((int)threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double g1 = red[0][0];
-            const double g2 = (red[1][0] - (double)beta[ch] * g1) / (double)gamma[ch];
-            double* st = stats + (long)(blockIdx.x % PSSR_STAT_STRIPES) * 2 * cin;
-            stat_add(st + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g1);
-            stat_add(st + cin + ch, (long)PSSR_STAT_STRIPES * 2 * cin, (float)g2);
-        }
-        __syncthreads();
-    }
-}
-
 template <typename T>
 __global__ void channel_sum_kernel(Ref x, double* out, long npix, int c, ChanMap m) {
     __shared__ float lds[TPB * 4];
@@ -904,31 +796,6 @@ int pssr_input_norm_bwd2(const void* dxcol_a, const void* dxcol_b, int xc, const
     if (gx > 512) gx = 512;
     DISPATCH_T(dtype, hipLaunchKernelGGL(input_norm_bwd_kernel<T>, dim3(gx, c), dim3(TPB), 0, (hipStream_t)s, (const T*)dxcol_a, (const T*)dxcol_b, xc,
                                          (const T*)dpatch, pc, patch > 0 ? patch : 1, x, pre_scale, pre_shift, mean, invstd, n, c, h, w, stats));
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
-
-int pssr_border_sums_nhwc(const void* x, int cs, int co, int n, int h, int w, int c, float* out, int slices, int dtype, pssr_stream_t s) {
-    PSSR_CHECK(x && out && n > 0 && h > 0 && w > 0 && c > 0, PSSR_ERR_ARG, "border_sums: bad args");
-    PSSR_CHECK(dtype == PSSR_BF16 || dtype == PSSR_F16, PSSR_ERR_UNSUPPORTED, "border_sums: 16-bit storage only (dtype %d)", dtype);
-    PSSR_CHECK(c % 8 == 0 && cs % 8 == 0 && co % 8 == 0 && co + c <= cs, PSSR_ERR_ARG, "border_sums: channel layout (%d,%d,%d)", cs, co, c);
-    PSSR_CHECK(slices >= 1 && slices <= 64, PSSR_ERR_ARG, "border_sums: slices=%d", slices);
-    if (dtype == PSSR_BF16)
-        hipLaunchKernelGGL(border_sums_kernel<bf16_t>, dim3((c + 63) / 64, 8, slices), dim3(TPB), 0, (hipStream_t)s, Ref{x, cs, co}, n, h, w, c, out);
-    else
-        hipLaunchKernelGGL(border_sums_kernel<f16_t>, dim3((c + 63) / 64, 8, slices), dim3(TPB), 0, (hipStream_t)s, Ref{x, cs, co}, n, h, w, c, out);
-    PSSR_LAUNCH_CHECK();
-    return PSSR_OK;
-}
-
-int pssr_input_norm_pre_stats(const float* weight, const float* dweight, int cout, int cin_w, int ci_begin, int cin, int h0, int r2,
-                              const float* bias_sums, const float* border_slices, int slices, const float* gamma, const float* beta,
-                              double* stats, pssr_stream_t s) {
-    PSSR_CHECK(weight && dweight && bias_sums && border_slices && gamma && beta && stats && slices >= 1, PSSR_ERR_ARG, "input_norm_pre_stats: null pointer");
-    PSSR_CHECK(cout > 0 && cin > 0 && ci_begin >= 0 && ci_begin + cin <= cin_w && h0 > 0 && r2 > 0 && cout == h0 * r2, PSSR_ERR_ARG,
-               "input_norm_pre_stats: shape (cout %d, cin %d+%d of %d, h0 %d, r2 %d)", cout, ci_begin, cin, cin_w, h0, r2);
-    hipLaunchKernelGGL(input_norm_pre_stats_kernel, dim3((cout + 63) / 64), dim3(TPB), 0, (hipStream_t)s, weight, dweight, cout, cin_w, ci_begin, cin, h0, r2,
-                       bias_sums, border_slices, slices, gamma, beta, stats);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -41,7 +41,6 @@ _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 # apply (bn_bwd_apply), relustats (relu_bwd_stats), unpack (partial-slab reduction of the weight gradients), gzero (flat gradient memset)
 _FUSE_DOUT = __import__("os").environ.get("PSSR_FUSE_DOUT", "1") != "0"
 _OVERWRITE_GRADS = __import__("os").environ.get("PSSR_OVERWRITE_GRADS", "1") != "0"
-_XCOL_LINEAR = __import__("os").environ.get("PSSR_XCOL_LINEAR", "1") != "0"
 _HEAD_FUSE = __import__("os").environ.get("PSSR_HEAD_FUSE", "1") != "0"      # eval mode: Reconstruction.conv inside pre's epilogue (EPI_HEADQ)
 _ABL = frozenset(x for x in __import__("os").environ.get("PSSR_ABLATE", "").split(",") if x)
 
@@ -838,36 +837,15 @@ class Engine:
             ops.f64_to_f32(bw.sum64, gpb)
         gb_pre = torch.empty_like(gpb)
         gb_pre[self.pre_perm_long] = gpb
-        gpb_sums = gpb              # pre's bias-gradient sums in its STORED channel order (sub-pixel major)
         grads[id(rec.pre.bias)] = gb_pre
         self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, feat, h0, 9, mode=0, ci_begin=0, ci_count=h0, n_perm=self.pre_perm, hh=h, ww=w)
-        # The input channel of `pre` needs no data gradient for its own sake: d(xcol) only feeds the two parameter gradients of the input
-        # BatchNorm, and by linearity those follow from this source's WEIGHT gradient, pre's bias sums and d(pre)'s border sums
-        # (csrc/elementwise.hip: input_norm_pre_stats_kernel) -- no 16-channel pass over the 1 GB d(pre) tensor (round 4: -0.14 ms of the
-        # c2 step by ablation).  The combine runs right behind the weight gradient's unpack, before any all-reduce may touch that slot.
-        lin = self.xcol_linear = (not self.atrous and _XCOL_LINEAR and gpb_sums is not None and code != L.F32 and not _ABLATE_XCOL
-                                  and "xwgrad" not in _ABL)
-        then, touches = None, ()
-        if lin:
-            st_in = p.bn_in
-            st_in.bstats.zero_()                        # (the end of the pass adds the first encoder block's share: no zeroing there)
-            if getattr(bw, "pre_border", None) is None:
-                slices = max(1, min(16, n * max(h, w) // 256))          # ~8 groups of 32 border pixels per workgroup
-                bw.pre_border = torch.empty(slices, 8, cpre_n, dtype=torch.float32, device=dev)
-            ops.border_sums_nhwc(bw.dpre, n, h, w, cpre_n, bw.pre_border, code)
-            norm = self.model.norm
-            bw.pre_bias_sums = gpb_sums
-
-            def then(slot):
-                ops.input_norm_pre_stats(rec.pre.weight, slot, h0, self.cin, r * r, gpb_sums, bw.pre_border, norm.weight, norm.bias, st_in.bstats)
-            touches = (st_in.bstats,)
         if not _ABLATE_XCOL and "xwgrad" not in _ABL:
             self._wgrad(p, grads, rec.pre, bw.dpre, cpre_n, p.xcol, self.xc, 1, mode=2, ci_begin=h0, ci_count=self.cin,
-                        n_perm=self.pre_perm, hh=h, ww=w, then=then, then_touches=touches)
+                        n_perm=self.pre_perm, hh=h, ww=w)
         self._ready(grads, list(rec.parameters()))
         cpre = self._convs[id(rec.pre)]
         ops.conv2d(bw.dpre, cpre_n, cpre.get("dgrad0", code), dfeat, h0, n=n, h=h, w=w)
-        if not _ABLATE_XCOL and "xdgrad" not in _ABL and not lin and not self.atrous:
+        if not _ABLATE_XCOL and "xdgrad" not in _ABL and not self.atrous:
             # the 16-channel data gradient of the input source only feeds the input BatchNorm's parameter gradients at the very end of the
             # pass: on the second stream it is off the dependent chain (the two queues of the backward phase end within 0.1 ms of each
             # other, so this pays only together with something that lightens the weight-gradient queue: PSSR_XCOL_SIDE)
@@ -882,9 +860,7 @@ class Engine:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, p, grads, conv_module, dy, cout, src, cin_pad, taps, *, mode=0, ci_begin=0, ci_count=None,
-               n_perm=None, pro=None, dy_blk=0, in_blk=0, hh, ww, center=False, dy_view_c=None, then=None, then_touches=()):
-        """``then(slot)`` (optional) runs right behind the unpack on the same stream (it reads the finished gradient slot);
-        ``then_touches``: buffers it writes, so that their next user on the launch stream waits for it (_before_write)."""
+               n_perm=None, pro=None, dy_blk=0, in_blk=0, hh, ww, center=False, dy_view_c=None):
         code = p.code
         esz = 4 if code == L.F32 else 2
         co_eff = cout if (cout * esz) % 16 == 0 else ops.pad_to(cout, 16)
@@ -909,10 +885,8 @@ class Engine:
             if "unpack" not in _ABL:
                 ops.unpack_conv_wgrad(pr, slot, mode=mode, ci_begin=ci_begin, ci_count=ci_count, n_perm=n_perm, k_pad=cin_pad,
                                       accumulate=not getattr(self, "_overwrite_grads", False))
-            if then is not None:
-                then(slot)
         if self._side_on:
-            self._on_side([dy, *then_touches], run)
+            self._on_side([dy], run)
         else:
             run()
 
@@ -1073,13 +1047,9 @@ class Engine:
             return self._finish_backward(grads)
         # ---- input BatchNorm parameters
         st = p.bn_in
-        if getattr(self, "xcol_linear", False):
-            self._before_write(st.bstats)       # pre's share was added behind its weight gradient (_head_backward), possibly on the second stream
-            ops.input_norm_bwd(bw.dxcol_a, None, x, st.mean, st.invstd, st.bstats, code)
-        else:
-            st.bstats.zero_()
-            self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream)
-            ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
+        st.bstats.zero_()
+        self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream)
+        ops.input_norm_bwd(bw.dxcol_a, bw.dxcol_b, x, st.mean, st.invstd, st.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         self.bn_coefs(st.bstats, float(n * h * w), m.norm.weight, st.mean, st.invstd, st.ca, st.cb, st.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet

@@ -189,22 +189,6 @@ def input_norm_bwd(dxcol_a, dxcol_b, x, mean, invstd, stats, dtype, pre_scale=1 
                                         L.stream_ptr()), "pssr_input_norm_bwd")
 
 
-def border_sums_nhwc(x, n, h, w, c, out, dtype, coff=0):
-    """out f32 [slices, 8, c]: per-channel sums over top row / bottom row / left column / right column / the four corners of every image,
-    slice z over every slices-th group of 32 border pixels (the consumer adds the slices in order)."""
-    L.check(L.lib().pssr_border_sums_nhwc(L.ptr(x), x.shape[-1], coff, n, h, w, c, L.ptr(out), out.shape[0], dtype, L.stream_ptr()),
-            "pssr_border_sums_nhwc")
-
-
-def input_norm_pre_stats(weight, dweight, h0, cin, r2, bias_sums, border_sums, gamma, beta, stats):
-    """stats (the input BatchNorm's backward statistic rows) += the share of Reconstruction.pre's input-channel source, from its weight
-    gradient ``dweight`` (same shape as ``weight`` [r2 * h0, h0 + cin, 3, 3]), pre's bias sums and d(pre)'s border sums."""
-    cout, cin_w = weight.shape[0], weight.shape[1]
-    L.check(L.lib().pssr_input_norm_pre_stats(L.ptr(weight), L.ptr(dweight), cout, cin_w, h0, cin, h0, r2, L.ptr(bias_sums), L.ptr(border_sums),
-                                              border_sums.shape[0], L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.stream_ptr()),
-            "pssr_input_norm_pre_stats")
-
-
 def maxpool2(x, out, n, h, w, c, dtype, in_coff=0, out_coff=0):
     L.check(L.lib().pssr_maxpool2(*_ref(x, in_coff), *_ref(out, out_coff), n, h, w, c, dtype, L.stream_ptr()), "pssr_maxpool2")
 

@@ -600,13 +600,9 @@ class RDEngine(Engine):
             return self._finish_backward(grads)
         # ---- input BatchNorm parameters (gradient sources: head im2col + stem patches)
         stn = p.bn_in
-        if getattr(self, "xcol_linear", False):     # the head's share was added behind pre's weight gradient (Engine._head_backward)
-            self._before_write(stn.bstats)
-            ops.input_norm_bwd2(None, None, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
-        else:
-            stn.bstats.zero_()
-            self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream: Engine._head_backward)
-            ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
+        stn.bstats.zero_()
+        self._before_write(bw.dxcol_b)          # (its producer may have run on the second stream: Engine._head_backward)
+        ops.input_norm_bwd2(None, bw.dxcol_b, bw.dxpatch, self.ps, x, stn.mean, stn.invstd, stn.bstats, code)
         dgam, dbet = self._gbuf(m.norm.weight), self._gbuf(m.norm.bias)
         self.bn_coefs(stn.bstats, float(n * h * w), m.norm.weight, stn.mean, stn.invstd, stn.ca, stn.cb, stn.cc, dgam, dbet)
         grads[id(m.norm.weight)], grads[id(m.norm.bias)] = dgam, dbet
