@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("in0_blk", C.c_int32), ("out_blk", C.c_int32), ("aux_blk", C.c_int32),
         ("out_scale", C.c_float), ("out_shift", C.c_float),
         ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
-        ("head_w", c_void_p), ("head_qa", c_void_p), ("head_q8", c_void_p),
+        ("head_w", c_void_p), ("head_q", c_void_p),
     ]
 
 

@@ -22,7 +22,7 @@ struct ConvArgs {
     unsigned* stamps;           // diagnostic build (-DPSSR_V3_STAMPS) only: per-(workgroup, wave) segment cycle sums
     int dbg;                    // diagnostic bits (tunable IGEMM_DBG; 0 in production): 1 skip the epilogue, 2 skip the multiply
     int ksplit; float* ws;      // split-K: blockIdx.y owns a chunk range, raw accumulators go to ws (single-source convs only)
-    const float* head_w; float* head_qa; float* head_q8;       // EPI_HEADQ (conv_v3_kernel<T, 128> only)
+    const float* head_w; float* head_q;                        // EPI_HEADQ (conv_v3_kernel<T, 128> only)
 };
 
 int launch_bf16(const ConvArgs& a, hipStream_t s);

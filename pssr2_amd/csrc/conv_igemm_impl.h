@@ -372,22 +372,32 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
 // the k slots 8 (lane >> 5) + i when element e = 8 ks + i of tile nj is taken as slot i of k-step (nj, ks).  So relu(acc + bias) is
 // rounded to the storage type (exactly the value the store would have written), packed in place, and four MFMAs per row tile against
 // the head weights arranged in the matching slot order (A operand: row = tap) leave q[tap][pixel] = sum over the wave's 64 channels
-// = one sub-pixel: rows 0-3 and 8 with lanes 0-31, rows 4-7 with lanes 32-63.  36 bytes per high-resolution pixel leave instead of 128.
+// = one sub-pixel: rows 0-3 and 8 with lanes 0-31, rows 4-7 with lanes 32-63.  36 bytes per high-resolution pixel leave instead of 128,
+// as nine 4-byte stores into the tap planes (16 lanes of a row = every fourth float of 256 bytes; the other three come from the waves
+// and workgroups that own the neighbouring sub-pixels and meet them in the XCD's L2).
+// (`hq`: [0, 576) Reconstruction.conv's weights [c][tap], [576, 704) pre's bias of the workgroup's 128 channels -- staged in LDS by
+// conv_headq_stage at kernel entry: fetched here, 64 dependent-latency loads per lane stood in front of every workgroup's epilogue)
+constexpr int HEADQ_LDS = (64 * 9 + 128) * 4;
+__device__ __forceinline__ void conv_headq_stage(const ConvArgs& p, float* hq, int tid, int n0) {
+    for (int i = tid; i < 64 * 9; i += 256) hq[i] = p.head_w[i];
+    if (tid < 128) hq[576 + tid] = (p.bias && n0 + tid < p.cout) ? p.bias[n0 + tid] : 0.f;
+}
+
 template <typename T, class C>
-__device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], int tid, int x0, int y0, int img0, int n0) {
+__device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], const float* hq, int tid, int x0, int y0, int img0, int n0) {
     using X = TT<T>;
     static_assert(sizeof(T) == 2 && C::NJ == 2 && C::MI == 4, "conv_v3 tiles of 128 channels");
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int h = lane >> 5, r = lane & 31;
     const int cbase = n0 + wn * 64;                  // first stored channel of this wave's 64 = sub * 64
-    const int sub = cbase >> 6, nsub = p.cout >> 6;
+    const int sub = cbase >> 6;                     // sub-pixel (i, j) = (sub >> 2, sub & 3) of the 4 x 4 block
     float bias[2][16];
     u32x4 wa[2][2];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) bias[nj][e] = p.bias ? p.bias[cbase + nj * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+        for (int e = 0; e < 16; ++e) bias[nj][e] = hq[576 + wn * 64 + nj * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float wv[8];
@@ -395,7 +405,7 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
             for (int i = 0; i < 8; ++i) {
                 const int e = 8 * ks + i;
                 const int c = nj * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;              // hidden channel of k slot (h, i)
-                wv[i] = r < 9 ? p.head_w[c * 9 + r] : 0.f;
+                wv[i] = r < 9 ? hq[c * 9 + r] : 0.f;
             }
             wa[nj][ks] = X::pack(wv);
         }
@@ -418,9 +428,19 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
         const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
         const int gy = y0 + ty, gx = x0 + tx;
         if (gy < p.H && gx < p.W) {
-            const long pix = ((long)img0 * p.H + gy) * p.W + gx;
-            *(float4*)(p.head_qa + (pix * nsub + sub) * 8 + 4 * h) = make_float4(q[0], q[1], q[2], q[3]);
-            if (h == 0) p.head_q8[pix * nsub + sub] = q[4];
+            // the product of tap (ky, kx) at high-resolution pixel P' belongs to output pixel P' - (ky - 1, kx - 1): stored there, in
+            // the tap's own plane, the nine planes add up position by position (no halo, no shuffle in the gather)
+            const int HH = 4 * p.H, WW = 4 * p.W;
+            const int Y0 = 4 * gy + (sub >> 2), X0 = 4 * gx + (sub & 3);
+            float* const qb = p.head_q + (long)img0 * HH * WW;
+            const long plane = (long)p.N * HH * WW;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                if (u == 4 && h) continue;
+                const int tap = u == 4 ? 8 : 4 * h + u;
+                const int Y = Y0 - (tap / 3 - 1), Xp = X0 - (tap % 3 - 1);
+                if (Y >= 0 && Y < HH && Xp >= 0 && Xp < WW) qb[tap * plane + (long)Y * WW + Xp] = q[u];
+            }
         }
     }
 }
@@ -956,8 +976,10 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
     // V3_LDS_PAD (KiB, experiment): unused LDS that keeps a second workgroup off the CU -- halves the input lines an XCD's L2 has to
     // hold between the K chunks of a tile
     int pad = pssr_tunables().v3_lds_pad * 1024;
-    if (C::LDS_BYTES + pro_lds + pad > 160 * 1024) pad = 160 * 1024 - C::LDS_BYTES - pro_lds;
-    hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds + pad, stream, p);
+    if (C::LDS_BYTES + pro_lds + pad + HEADQ_LDS > 160 * 1024) pad = 160 * 1024 - C::LDS_BYTES - pro_lds - HEADQ_LDS;
+    const int hq_lds = a.epi == PSSR_EPI_HEADQ ? HEADQ_LDS : 0;          // (no BatchNorm prologue table with it: pre reads activated inputs)
+    PSSR_CHECK(!(hq_lds && pro_lds), PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ with a BatchNorm prologue");
+    hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds + pad + hq_lds, stream, p);
     if (ksplit > 1)
         hipLaunchKernelGGL((conv_splitk_finish3_kernel<T, BN>), dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, p);
     PSSR_LAUNCH_CHECK();

@@ -134,58 +134,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ inference: gather of the tap products
-// Second half of PSSR_EPI_HEADQ (conv_igemm_impl.h: conv_headq_epilogue): qa[lrpix][sub][0..7], q8[lrpix][sub] hold, for the
-// high-resolution pixel (r y + i, r x + j) = (low-resolution pixel (y, x), sub-pixel i r + j), its nine products with
-// Reconstruction.conv's taps; out[p] = bias + sum_tap q[tap][p + off(tap)] (zero outside the image).  Every product is used exactly
-// once, so the kernel is one coalesced read of both arrays: a workgroup stages the products of an 8 x 8 block of low-resolution pixels
-// plus a ring of one as nine high-resolution tap planes (59 KB) and each thread sums 4 outputs of one high-resolution column.
-template <int R>
-__global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restrict__ qa, const float* __restrict__ q8, const float* __restrict__ bias,
-                                                            float* __restrict__ out, int n, int h, int w, float out_scale, float out_shift) {
-    constexpr int R2 = R * R, TB = 8, HB = TB + 2, HR = HB * R, PITCH = HR + 1, PLANE = HR * PITCH + 1;
-    static_assert(R == 4, "4 x upscaling");
-    // nine tap planes of the (8 + 2) x 4 = 40 x 40 high-resolution block, rows 41 floats apart: in the sum below the 32 lanes of a read
-    // group walk 32 consecutive floats of one row (conflict-free); the staging stores of a lane pair (taps 0-3 / 4-7 of one pixel) go to
-    // planes 4 * PLANE floats = 4 banks apart
-    extern __shared__ __attribute__((aligned(16))) float Lq[];       // [9][PLANE]
-    const int tid = threadIdx.x;
-    const int bx = blockIdx.x * TB, by = blockIdx.y * TB, img = blockIdx.z;
-    for (int i = tid; i < HB * HB * R2 * 2; i += 256) {
-        const int part = i & 1, ps = i >> 1;                // float4 part 0 / 1 of the 8 first taps of (halo pixel, sub-pixel) ps
-        const int sub = ps % R2, hp = ps / R2;
-        const int hy = hp / HB, hx = hp % HB;
-        const int ly = by + hy - 1, lx = bx + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ly >= 0 && ly < h && lx >= 0 && lx < w)
-            v = *(const float4*)(qa + ((((long)img * h + ly) * w + lx) * R2 + sub) * 8 + 4 * part);
-        float* d = Lq + (4 * part) * PLANE + (hy * R + sub / R) * PITCH + hx * R + sub % R;
-        d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
-    }
-    for (int i = tid; i < HB * HB * R2; i += 256) {
-        const int sub = i % R2, hp = i / R2;
-        const int hy = hp / HB, hx = hp % HB;
-        const int ly = by + hy - 1, lx = bx + hx - 1;
-        float v = 0.f;
-        if (ly >= 0 && ly < h && lx >= 0 && lx < w) v = q8[(((long)img * h + ly) * w + lx) * R2 + sub];
-        Lq[8 * PLANE + (hy * R + sub / R) * PITCH + hx * R + sub % R] = v;
-    }
-    __syncthreads();
+// ------------------------------------------------------------------------------------------------ inference: sum of the tap planes
+// Second half of PSSR_EPI_HEADQ (conv_igemm_impl.h: conv_headq_epilogue stores every tap product at the output position it belongs
+// to): out = (bias + sum of the nine planes) * scale + shift, four outputs (one float4 of each plane) per thread.
+__global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restrict__ q, const float* __restrict__ bias, float* __restrict__ out,
+                                                            long total4, long plane4, float out_scale, float out_shift) {
     const float b = bias ? bias[0] : 0.f;
-    // thread -> column xl (0 .. 31) of the block's 32 x 32 outputs, rows yl = tid / 32 + 8 k
-    const int xl = tid & 31;
-    const int X = bx * R + xl;
-    if (X >= w * R) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = make_float4(b, b, b, b);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int yl = (tid >> 5) + 8 * k;
-        const int Y = by * R + yl;
-        if (Y >= h * R) continue;
-        float s = b;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            s += Lq[tap * PLANE + (yl + R + tap / 3 - 1) * PITCH + xl + R + tap % 3 - 1];
-        out[((long)img * h * R + Y) * ((long)w * R) + X] = fmaf(s, out_scale, out_shift);
+        for (int t = 0; t < 9; ++t) {
+            const float4 v = ((const float4*)q)[t * plane4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        ((float4*)out)[i] = make_float4(fmaf(s.x, out_scale, out_shift), fmaf(s.y, out_scale, out_shift), fmaf(s.z, out_scale, out_shift),
+                                        fmaf(s.w, out_scale, out_shift));
     }
 }
 
@@ -684,19 +647,13 @@ int pssr_head_conv_fwd(const void* in, int in_cs, int in_co, int in_blk, const f
     return PSSR_OK;
 }
 
-int pssr_head_q_gather(const float* qa, const float* q8, const float* bias, float* out_nchw, int n, int h, int w, int r, float out_scale,
-                       float out_shift, pssr_stream_t s) {
-    PSSR_CHECK(qa && q8 && out_nchw && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "head_q_gather: bad args");
-    PSSR_CHECK(r == 4, PSSR_ERR_UNSUPPORTED, "head_q_gather: r=%d (4 x upscaling only)", r);
-    PSSR_CHECK(n <= 65535 && (h + 7) / 8 <= 65535, PSSR_ERR_ARG, "head_q_gather: grid");
-    constexpr int LDS = 9 * (40 * 41 + 1) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)head_q_gather_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(head_q_gather_kernel<4>, dim3((w + 7) / 8, (h + 7) / 8, n), dim3(256), LDS, (hipStream_t)s, qa, q8, bias, out_nchw, n, h, w,
-                       out_scale, out_shift);
+int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int hh, int ww, float out_scale, float out_shift,
+                       pssr_stream_t s) {
+    PSSR_CHECK(q && out_nchw && n > 0 && hh > 0 && ww > 0 && ww % 4 == 0, PSSR_ERR_ARG, "head_q_gather: bad args");
+    const long total4 = (long)n * hh * ww / 4;
+    const long blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(head_q_gather_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)s, q, bias, out_nchw, total4,
+                       total4, out_scale, out_shift);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -59,9 +59,9 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
            x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
            pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
            aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None,
-           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False, head_w=None, head_qa=None, head_q8=None):
+           in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False, head_w=None, head_q=None):
     """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff).  EPI_HEADQ: ``out`` is unused (pass
-    ``head_qa``), the tap products go to ``head_qa`` / ``head_q8``."""
+    ``head_q``), the tap products go to the nine planes ``head_q`` [9, n, 4h, 4w] f32 (zeroed once by the caller)."""
     d = L.ConvDesc()
     d.dtype = w0.dtype
     d.n, d.h, d.w = n, h, w
@@ -83,7 +83,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
         d.out_cstride, d.out_coff = cout, 0
     if epilogue == L.EPI_HEADQ:
         d.out_cstride, d.out_coff = cout, 0
-        d.head_w, d.head_qa, d.head_q8 = L.ptr(head_w), L.ptr(head_qa), L.ptr(head_q8)
+        d.head_w, d.head_q = L.ptr(head_w), L.ptr(head_q)
     ws_bytes = L.lib().pssr_conv2d_workspace_bytes(C.byref(d))      # > 0: the library wants to split K (under-filled grid)
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device)
@@ -536,9 +536,9 @@ def head_q_supported(dtype, h0, cout, r, h, w):
     return dtype != L.F32 and h0 == 64 and cout == 1 and r == 4 and h >= 16 and w >= 16 and L.lib().pssr_get_option(b"IGEMM_V3") > 0
 
 
-def head_q_gather(qa, q8, bias, out, n, h, w, r, out_scale, out_shift):
-    L.check(L.lib().pssr_head_q_gather(L.ptr(qa), L.ptr(q8), L.ptr(bias), L.ptr(out), n, h, w, r, C.c_float(out_scale), C.c_float(out_shift),
-                                       L.stream_ptr()), "pssr_head_q_gather")
+def head_q_gather(q, bias, out, n, hh, ww, out_scale, out_shift):
+    L.check(L.lib().pssr_head_q_gather(L.ptr(q), L.ptr(bias), L.ptr(out), n, hh, ww, C.c_float(out_scale), C.c_float(out_shift), L.stream_ptr()),
+            "pssr_head_q_gather")
 
 
 def head_conv_bwd_rows(g, g_scale, weight, act, dact, blk, dw_rows, bias_rows, n, h, w, cin, cout, dtype):

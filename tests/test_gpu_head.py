@@ -88,7 +88,7 @@ def test_inference_head_inside_pre_epilogue(monkeypatch, dt, shape):
         with torch.no_grad():
             outs[fuse] = model(x).float().clone()
         plan = list(model._engine.plans.values())[-1]
-        assert (getattr(plan, "head_qa", None) is not None) == fuse or not fuse
+        assert (getattr(plan, "head_q", None) is not None) == fuse or not fuse
     a, b = outs[True], outs[False]
     assert a.shape == (n, 1, 4 * h, 4 * w) and torch.isfinite(a).all()
     err = float((a - b).abs().max())
