@@ -75,11 +75,11 @@ def kernel_traffic(mode, symbol):
 
 def pass_traffic(mode):
     """Counter HBM bytes of one whole pass (every kernel of a training step / an inference batch) from the same table, or None.  The
-    number of passes the counters saw = the launches of a once-per-pass kernel (AdamW for training, the head's forward for inference)."""
+    number of passes the counters saw = the launches of a once-per-pass kernel (AdamW for training, the input im2col for inference)."""
     t = traffic_table(mode)
     if not t:
         return None
-    once = "adamw_kernel" if mode.endswith("train") else "head_fwd_kernel"
+    once = "adamw_kernel" if mode.endswith("train") else "input_im2col_kernel"
     passes = sum(r.get("launches", 0) for name, r in t["kernels"].items() if once in name)
     if not passes:
         return None

@@ -113,8 +113,11 @@ enum {
 
 enum {
     PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
-    PSSR_FLAG_STATS = 2   /* accumulate per-channel f64 sums into `stats`:
+    PSSR_FLAG_STATS = 2,  /* accumulate per-channel f64 sums into `stats`:
                              EPI_STORE: [sum v, sum v^2]; EPI_DGRAD_MASK: [sum g, sum g*xhat] */
+    PSSR_FLAG_AFFINE = 4  /* EPI_STORE, 16-bit storage, not with FLAG_STATS: out = (acc + bias) * aux_scale + aux_shift (then FLAG_RELU):
+                             an eval-mode BatchNorm (+ ReLU) applied by the PRODUCING convolution on its f32 accumulators
+                             (_blocks.py:28-32 in eval mode), so that the next layer's loader needs no prologue */
 };
 
 typedef struct pssr_conv_desc {

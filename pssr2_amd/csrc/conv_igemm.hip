@@ -66,6 +66,12 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     }
     if (d->epilogue == PSSR_EPI_DGRAD_GELU)
         PSSR_CHECK(d->aux && d->aux_coff % 4 == 0 && d->aux_cstride % 4 == 0, PSSR_ERR_ARG, "conv2d: GELU backward needs the pre-activation as aux");
+    if (d->flags & PSSR_FLAG_AFFINE) {
+        PSSR_CHECK(d->epilogue == PSSR_EPI_STORE && !(d->flags & PSSR_FLAG_STATS) && d->aux_scale && d->aux_shift, PSSR_ERR_ARG,
+                   "conv2d: FLAG_AFFINE needs EPI_STORE without statistics and aux_scale / aux_shift");
+        PSSR_CHECK(esz == 2 && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 && pssr_tunables().conv_epi8, PSSR_ERR_UNSUPPORTED,
+                   "conv2d: FLAG_AFFINE needs 16-bit storage and 8-channel aligned outputs");
+    }
     if (d->flags & PSSR_FLAG_STATS) {
         PSSR_CHECK(d->stats != nullptr, PSSR_ERR_ARG, "conv2d: stats buffer missing");
         PSSR_CHECK(d->epilogue != PSSR_EPI_DGRAD_MASK || (d->aux_mean && d->aux_invstd), PSSR_ERR_ARG, "conv2d: mask stats need mean/invstd");

@@ -219,8 +219,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 // (lane & 31), channels (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of a 32-channel tile, i.e. runs of 4 consecutive channels = one
 // ds_write_b128 each (a quarter of the LDS write instructions of the plain layout, whose 128 scalar writes per lane were most of a
 // K = 576 layer's epilogue).  Rows are then BN + 4 floats apart (the 16 lanes of a write group hit 16 different bank quads).
-template <typename T, int BN, class C, int EPI, bool STATS, bool TR = false>
+template <typename T, int BN, class C, int EPI, bool STATS, bool TR = false, bool AFF = false>
 __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], char* smem, int tid, int x0, int y0, int img0, int n0) {
+    static_assert(!AFF || (EPI == PSSR_EPI_STORE && !STATS), "FLAG_AFFINE: EPI_STORE without statistics");
     using X = TT<T>;
     static_assert(sizeof(T) == 2, "8-channel pieces are 16 bytes of a 16-bit type");
     const int lane = tid & 63, wave = tid >> 6;
@@ -272,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     for (int e = 0; e < 8; ++e) { xs[e] = 0.f; xh[e] = 0.f; xm[e] = 0.f; xi[e] = 0.f; }
     if (n_ok) {
         if ((EPI == PSSR_EPI_STORE || EPI == PSSR_EPI_TAIL) && p.bias) { load4(p.bias + n_base, bias); load4(p.bias + n_base + 4, bias + 4); }
-        if (EPI == PSSR_EPI_TAIL || EPI == PSSR_EPI_DGRAD_MASK) {
+        if (EPI == PSSR_EPI_TAIL || EPI == PSSR_EPI_DGRAD_MASK || AFF) {
             load4(p.aux_scale + n_base, xs); load4(p.aux_scale + n_base + 4, xs + 4);
             load4(p.aux_shift + n_base, xh); load4(p.aux_shift + n_base + 4, xh + 4);
         }
@@ -313,7 +314,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
             if constexpr (EPI == PSSR_EPI_DGRAD_GELU) gelu_grad_mul_vec<T, 8>(a, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (EPI == PSSR_EPI_STORE) v[e] = fmaxf(v[e] + bias[e], relu_lo);
+                if (EPI == PSSR_EPI_STORE) v[e] = fmaxf(AFF ? fmaf(v[e] + bias[e], xs[e], xh[e]) : v[e] + bias[e], relu_lo);
                 else if (EPI == PSSR_EPI_TAIL) v[e] = fmaxf(v[e] + bias[e] + fmaf(a[e], xs[e], xh[e]), 0.f);
                 else if (EPI == PSSR_EPI_DGRAD_GELU) {}
                 else {
@@ -453,6 +454,7 @@ __device__ __forceinline__ void conv_epilogue8_any(const ConvArgs& p, f32x16 (&a
     switch (p.epi) {
     case PSSR_EPI_STORE:
         if (st) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, true, TR>(p, acc, smem, tid, x0, y0, img0, n0);
+        else if (p.flags & PSSR_FLAG_AFFINE) conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false, TR, true>(p, acc, smem, tid, x0, y0, img0, n0);
         else conv_epilogue8<T, BN, C, PSSR_EPI_STORE, false, TR>(p, acc, smem, tid, x0, y0, img0, n0);
         return;
     case PSSR_EPI_TAIL: conv_epilogue8<T, BN, C, PSSR_EPI_TAIL, false, TR>(p, acc, smem, tid, x0, y0, img0, n0); return;

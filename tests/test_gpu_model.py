@@ -428,3 +428,28 @@ def test_materialised_activations_and_side_stream_xcol_give_the_same_gradients(g
     for a, b in zip(base, alt):
         for n in a:
             assert torch.equal(a[n], b[n]), n
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_eval_batchnorm_in_the_producing_epilogue(golden, monkeypatch, dt):
+    """Round 4 (eval mode, 16-bit storage): BatchNorm + ReLU behind a block convolution applied by that convolution's epilogue on the f32
+    accumulators (PSSR_FLAG_AFFINE) instead of by the next loader's prologue on the stored 16-bit map.  Same network function: both
+    forms sit within 16-bit storage error of the exact-f32 engine, the epilogue form no further away than the prologue form."""
+    import pssr2_amd.engine as E
+    g = golden("model.npz")
+    outs = {}
+    for name, aff, cdt in (("f32", False, torch.float32), ("pro", False, dt), ("epi", True, dt)):
+        monkeypatch.setattr(E, "_EVAL_AFFINE", aff)
+        model, x = _load(g, "tiny")
+        model.compute_dtype = cdt
+        model.infer_dtype = cdt
+        model.eval()
+        with torch.no_grad():
+            outs[name] = model(x).float().clone()
+    e_pro = float((outs["pro"] - outs["f32"]).abs().max())
+    e_epi = float((outs["epi"] - outs["f32"]).abs().max())
+    scale = float(outs["f32"].abs().max())
+    print(f"eval affine in the epilogue: max |out - f32| = {e_epi:.3e} (prologue form {e_pro:.3e}), output scale {scale:.1f}")
+    assert not torch.equal(outs["pro"], outs["epi"])            # the two forms really are different code paths
+    assert e_epi <= 1.25 * e_pro + 1e-3 * scale, (e_epi, e_pro)
+    assert abs(_psnr(outs["epi"], outs["f32"]) - _psnr(outs["pro"], outs["f32"])) < 6.0
