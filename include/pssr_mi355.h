@@ -115,6 +115,9 @@ enum {
     PSSR_FLAG_RELU = 1,   /* EPI_STORE: relu after bias (Reconstruction.pre, _blocks.py:16)   */
     PSSR_FLAG_STATS = 2,  /* accumulate per-channel f64 sums into `stats`:
                              EPI_STORE: [sum v, sum v^2]; EPI_DGRAD_MASK: [sum g, sum g*xhat] */
+    PSSR_FLAG_HEADQ = 8,  /* EPI_STORE (with FLAG_RELU): store the activation AND the tap planes of PSSR_EPI_HEADQ (same conditions, head_w /
+                             head_q set): the training form -- `pre`'s activation is kept for the backward pass, Reconstruction.conv's
+                             forward still needs no pass over it */
     PSSR_FLAG_AFFINE = 4  /* EPI_STORE, 16-bit storage, not with FLAG_STATS: out = (acc + bias) * aux_scale + aux_shift (then FLAG_RELU):
                              an eval-mode BatchNorm (+ ReLU) applied by the PRODUCING convolution on its f32 accumulators
                              (_blocks.py:28-32 in eval mode), so that the next layer's loader needs no prologue */

@@ -51,7 +51,10 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     PSSR_CHECK(d->prologue >= 0 && d->prologue <= PSSR_PRO_GELU, PSSR_ERR_ARG, "conv2d: prologue=%d", d->prologue);
     PSSR_CHECK(d->prologue != PSSR_PRO_BN_RELU || (d->pro_scale && d->pro_shift), PSSR_ERR_ARG, "conv2d: prologue needs scale/shift");
     PSSR_CHECK(d->epilogue >= 0 && d->epilogue <= 5, PSSR_ERR_ARG, "conv2d: epilogue=%d", d->epilogue);
-    if (d->epilogue == PSSR_EPI_HEADQ) {
+    if (d->flags & PSSR_FLAG_HEADQ)
+        PSSR_CHECK(d->epilogue == PSSR_EPI_STORE && !(d->flags & (PSSR_FLAG_STATS | PSSR_FLAG_AFFINE)) && (d->flags & PSSR_FLAG_RELU), PSSR_ERR_ARG,
+                   "conv2d: FLAG_HEADQ goes with EPI_STORE | FLAG_RELU only");
+    if (d->epilogue == PSSR_EPI_HEADQ || (d->flags & PSSR_FLAG_HEADQ)) {
         PSSR_CHECK(query_ws || (d->head_w && d->head_q), PSSR_ERR_ARG, "conv2d: EPI_HEADQ needs head_w / head_q");
         PSSR_CHECK(esz == 2 && d->cout == 1024 && d->taps0 == 9 && d->w >= 16 && d->h >= 16 && d->prologue != PSSR_PRO_GELU && !(d->flags & PSSR_FLAG_STATS),
                    PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs 16-bit storage, a 3x3 source, cout = 16 x 64 (4 x upscaling) and at least 16x16 pixels");
@@ -89,8 +92,9 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     a.stats = d->stats;
     a.in0_blk = d->in0_blk; a.out_blk = d->out_blk; a.aux_blk = d->aux_blk;
     a.out_scale = d->out_scale; a.out_shift = d->out_shift;
-    a.head_w = a.epi == PSSR_EPI_HEADQ ? d->head_w : nullptr;
-    a.head_q = a.epi == PSSR_EPI_HEADQ ? d->head_q : nullptr;
+    const bool headq = a.epi == PSSR_EPI_HEADQ || (a.flags & PSSR_FLAG_HEADQ);
+    a.head_w = headq ? d->head_w : nullptr;
+    a.head_q = headq ? d->head_q : nullptr;
     a.tiles_x = a.tiles_y = a.tiles_n = 0;
     a.epi8 = esz == 2 && d->epilogue != PSSR_EPI_FINAL && d->cout % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 &&
              (d->epilogue == PSSR_EPI_STORE || d->epilogue == PSSR_EPI_HEADQ || (d->aux_coff % 8 == 0 && d->aux_cstride % 8 == 0));

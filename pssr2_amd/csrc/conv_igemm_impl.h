@@ -958,7 +958,7 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
     const long blocks = (long)p.tiles_x * p.tiles_y * a.N * p.tiles_n;
     PSSR_CHECK(blocks > 0 && blocks < (1L << 31), PSSR_ERR_ARG, "conv2d: bad grid %ld", blocks);
     int ksplit = 1;
-    if (a.epi != PSSR_EPI_FINAL && a.epi != PSSR_EPI_HEADQ && blocks < 192 && a.nchunks[0] >= 8) {
+    if (a.epi != PSSR_EPI_FINAL && a.epi != PSSR_EPI_HEADQ && !(a.flags & PSSR_FLAG_HEADQ) && blocks < 192 && a.nchunks[0] >= 8) {
         ksplit = (int)((256 + blocks - 1) / blocks);
         if (ksplit > a.nchunks[0] / 4) ksplit = a.nchunks[0] / 4;
         if (ksplit > 8) ksplit = 8;
@@ -979,7 +979,7 @@ int launch3_t(const ConvArgs& a, hipStream_t stream) {
     // hold between the K chunks of a tile
     int pad = pssr_tunables().v3_lds_pad * 1024;
     if (C::LDS_BYTES + pro_lds + pad + HEADQ_LDS > 160 * 1024) pad = 160 * 1024 - C::LDS_BYTES - pro_lds - HEADQ_LDS;
-    const int hq_lds = a.epi == PSSR_EPI_HEADQ ? HEADQ_LDS : 0;          // (no BatchNorm prologue table with it: pre reads activated inputs)
+    const int hq_lds = (a.epi == PSSR_EPI_HEADQ || (a.flags & PSSR_FLAG_HEADQ)) ? HEADQ_LDS : 0;          // (no BatchNorm prologue table with it: pre reads activated inputs)
     PSSR_CHECK(!(hq_lds && pro_lds), PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ with a BatchNorm prologue");
     hipLaunchKernelGGL((conv_v3_kernel<T, BN>), dim3((unsigned)blocks, ksplit), dim3(256), C::LDS_BYTES + pro_lds + pad + hq_lds, stream, p);
     if (ksplit > 1)
@@ -1107,19 +1107,19 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
         // (16x32-pixel x 64-channel v3 tiles for these wider layers too -- twice the workgroups, two rounds that drift apart instead of
         // one in lockstep -- measured 49.3 vs 47.7 us on 128 -> 128 @64^2: no)
         if constexpr (sizeof(T) == 2) {
-            if (a.epi == PSSR_EPI_HEADQ) {            // the tap-product epilogue exists in the conv_v3 tiles only (shape checked by the entry)
+            if (a.epi == PSSR_EPI_HEADQ || (a.flags & PSSR_FLAG_HEADQ)) {            // the tap-product epilogue exists in the conv_v3 tiles only (shape checked by the entry)
                 PSSR_CHECK(a.epi8 && pssr_tunables().igemm_v3, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs the conv_v3 loop");
                 return launch3_t<T, 128>(a, s);
             }
         }
-        PSSR_CHECK(a.epi != PSSR_EPI_HEADQ, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs 16-bit storage");
+        PSSR_CHECK(a.epi != PSSR_EPI_HEADQ && !(a.flags & PSSR_FLAG_HEADQ), PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs 16-bit storage");
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 128>(a)) return launch3_t<T, 128>(a, s); }
         if constexpr (sizeof(T) == 2) {
             if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
         }
         return launch_geo<T, 128>(a, s);
     }
-    PSSR_CHECK(a.epi != PSSR_EPI_HEADQ, PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs cout > 64");
+    PSSR_CHECK(a.epi != PSSR_EPI_HEADQ && !(a.flags & PSSR_FLAG_HEADQ), PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs cout > 64");
     if (a.cout > 32) {
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 64>(a)) return launch3_t<T, 64>(a, s); }
         return launch_geo<T, 64>(a, s);

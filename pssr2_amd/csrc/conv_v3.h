@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     }
     const float* const tab_t = tab + half * 2 * EPS;
     if constexpr (BN == 128) {
-        if (p.epi == PSSR_EPI_HEADQ) conv_headq_stage(p, tab, tid, n0);      // (published by the __syncthreads of the loop prologue)
+        if (p.epi == PSSR_EPI_HEADQ || (p.flags & PSSR_FLAG_HEADQ)) conv_headq_stage(p, tab, tid, n0);      // (published by the __syncthreads of the loop prologue)
     }
 
 #ifdef PSSR_V3_STAMPS
@@ -408,7 +408,10 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
         return;
     }
     if constexpr (BN == 128) {
-        if (p.epi == PSSR_EPI_HEADQ) { conv_headq_epilogue<T, C>(p, acc, (const float*)(smem + C::LDS_BYTES), tid, x0, y0, img0, n0); return; }
+        if (p.epi == PSSR_EPI_HEADQ || (p.flags & PSSR_FLAG_HEADQ)) {
+            conv_headq_epilogue<T, C>(p, acc, (const float*)(smem + C::LDS_BYTES), tid, x0, y0, img0, n0);
+            if (p.epi == PSSR_EPI_HEADQ) return;          // FLAG_HEADQ (training): the activation is stored as well
+        }
     }
     conv_epilogue8_any<T, BN, C, true>(p, acc, smem, tid, x0, y0, img0, n0);
 #ifdef PSSR_V3_STAMPS

@@ -83,6 +83,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
         d.out_cstride, d.out_coff = cout, 0
     if epilogue == L.EPI_HEADQ:
         d.out_cstride, d.out_coff = cout, 0
+    if epilogue == L.EPI_HEADQ or flags & L.FLAG_HEADQ:
         d.head_w, d.head_q = L.ptr(head_w), L.ptr(head_q)
     ws_bytes = L.lib().pssr_conv2d_workspace_bytes(C.byref(d))      # > 0: the library wants to split K (under-filled grid)
     if ws_bytes > 0:

@@ -95,3 +95,30 @@ def test_inference_head_inside_pre_epilogue(monkeypatch, dt, shape):
     assert err <= 2e-3 * max(1.0, float(b.abs().max()) / 128), err
     ua, ub = a.clamp(0, 255).to(torch.uint8), b.clamp(0, 255).to(torch.uint8)
     assert float((ua != ub).float().mean()) <= 1e-3 and int((ua.int() - ub.int()).abs().max()) <= 1
+
+
+def test_training_head_keeps_the_activation_and_the_tap_planes(monkeypatch):
+    """FLAG_HEADQ (training): `pre` stores its activation for the backward pass exactly as before (bit for bit) and emits the tap planes in
+    the same launch; the network output equals the stored-activation head's up to f32 summation order, and so do the gradients."""
+    import pssr2_amd.engine as E
+    from pssr2_amd.models import ResUNet
+    torch.manual_seed(5)
+    x = (torch.rand(2, 1, 32, 32) * 255).cuda()
+    tgt = (torch.rand(2, 1, 128, 128) * 255).cuda()
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(E, "_HEAD_FUSE", fuse)
+        torch.manual_seed(7)
+        model = ResUNet(hidden=[64, 128], depth=1).cuda().train()
+        model.compute_dtype = torch.bfloat16
+        y = model(x)
+        torch.nn.functional.mse_loss(y / 255, tgt / 255).backward()
+        torch.cuda.synchronize()
+        plan = list(model._engine.plans.values())[-1]
+        res[fuse] = (y.detach().float().clone(), plan.pre.clone(), {n: p.grad.clone() for n, p in model.named_parameters()})
+    (ya, pa, ga), (yb, pb, gb) = res[True], res[False]
+    assert torch.equal(pa, pb)
+    assert float((ya - yb).abs().max()) <= 2e-3 * max(1.0, float(yb.abs().max()) / 128)
+    for n in ga:
+        scale = float(gb[n].abs().max()) + 1e-12
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-2 * scale, n
