@@ -121,7 +121,7 @@ class ConvTimer:
         self.orig = None
 
     def install(self):
-        from pssr2_amd import ops
+        from pssr2_amd import ops, _lib as L_
         self.orig = ops.conv2d
         timer = self
 
@@ -140,7 +140,16 @@ class ConvTimer:
             nbytes = 2.0 * (npix * (k0 + k1 + cout) + cout * (w0.taps * k0 + k1))
             if kw.get("aux") is not None:
                 nbytes += 2.0 * npix * cout
-            timer.events.append((e0, e1, flops, nbytes))
+            # Reconstruction.pre's forward with Reconstruction.conv's forward in its epilogue (FLAG_HEADQ / EPI_HEADQ): the launch also does
+            # the head's 2 x 9 x 64 FLOP per high-resolution pixel and writes the nine f32 tap planes (36 B per high-resolution pixel);
+            # in eval mode (EPI_HEADQ) it does not write its own activation
+            fused = bool(kw.get("flags", 0) & L_.FLAG_HEADQ) or kw.get("epilogue", 0) == L_.EPI_HEADQ
+            if fused:
+                flops += 2.0 * 9 * npix * cout
+                nbytes += 36.0 * npix * (cout // 64)
+                if kw.get("epilogue", 0) == L_.EPI_HEADQ:
+                    nbytes -= 2.0 * npix * cout
+            timer.events.append((e0, e1, flops, nbytes, fused))
             return r
         ops.conv2d = timed
         import pssr2_amd.engine as E
@@ -155,11 +164,17 @@ class ConvTimer:
     def summary(self):
         if not self.events:
             return None
-        ms = [a.elapsed_time(b) for a, b, _, _ in self.events]
+        ms = [e[0].elapsed_time(e[1]) for e in self.events]
         tot_ms, tot_fl, tot_b = sum(ms), sum(e[2] for e in self.events), sum(e[3] for e in self.events)
         n = len(ms)
-        return dict(launches=n, avg_us=1e3 * tot_ms / n, tflops=tot_fl / (tot_ms * 1e-3) / 1e12, gflop_per_launch=tot_fl / n / 1e9,
-                    bytes_per_launch=tot_b / n)
+        out = dict(launches=n, avg_us=1e3 * tot_ms / n, tflops=tot_fl / (tot_ms * 1e-3) / 1e12, gflop_per_launch=tot_fl / n / 1e9,
+                   bytes_per_launch=tot_b / n, fused_head=None)
+        fz = [(m, e) for m, e in zip(ms, self.events) if e[4]]
+        if fz and len(fz) < n:
+            f_ms, f_fl = sum(m for m, _ in fz), sum(e[2] for _, e in fz)
+            out["fused_head"] = dict(launches=len(fz), avg_us=1e3 * f_ms / len(fz), tflops=f_fl / (f_ms * 1e-3) / 1e12,
+                                     others_tflops=(tot_fl - f_fl) / ((tot_ms - f_ms) * 1e-3) / 1e12, others_avg_us=1e3 * (tot_ms - f_ms) / (n - len(fz)))
+        return out
 
 
 class HbmTimer:
@@ -192,7 +207,9 @@ class HbmTimer:
         # head_conv_bwd_rows(g, g_scale, weight, act, dact, blk, dw_rows, bias_rows, n, h, w, cin, cout, dtype)
         bwd_b = lambda g, gs, wt, act, dact, blk, dwr, br, n, h, w, cin, cout, dt: n * h * w * (2 * cin * esz(dt) + 4 * cout)
         adam_b = lambda p, *a, **kw: 28 * p.numel()
-        for name, nb in (("head_conv_fwd", fwd_b), ("head_conv_bwd_rows", bwd_b), ("adamw_step_dev", adam_b), ("adamw_step", adam_b)):
+        # head_q_gather(q, bias, out, n, hh, ww, scale, shift): nine f32 planes read, the f32 image written
+        gat_b = lambda q, b, out, n, hh, ww, *a, **kw: 40 * n * hh * ww
+        for name, nb in (("head_conv_fwd", fwd_b), ("head_q_gather", gat_b), ("head_conv_bwd_rows", bwd_b), ("adamw_step_dev", adam_b), ("adamw_step", adam_b)):
             self.orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self.orig[name], nb))
 
@@ -203,8 +220,10 @@ class HbmTimer:
 
     def objects(self, mode="train"):
         out = []
-        sym = {"head_conv_fwd": "head_fwd_kernel", "head_conv_bwd_rows": "head_bwd_kernel", "adamw_step_dev": "adamw_kernel", "adamw_step": "adamw_kernel"}
+        sym = {"head_conv_fwd": "head_fwd_kernel", "head_q_gather": "head_q_gather_kernel", "head_conv_bwd_rows": "head_bwd_kernel",
+               "adamw_step_dev": "adamw_kernel", "adamw_step": "adamw_kernel"}
         label = {"head_conv_fwd": "head_fwd_kernel (Reconstruction.conv forward on the pixel-shuffled HR tensor)",
+                 "head_q_gather": "head_q_gather_kernel (sum of the nine tap planes Reconstruction.pre's epilogue wrote: what is left of Reconstruction.conv's forward)",
                  "head_conv_bwd_rows": "head_bwd_kernel (its data + weight gradient + bias sums in one pass)",
                  "adamw_step_dev": "adamw_kernel (fused AdamW over the flat parameter buffer)", "adamw_step": "adamw_kernel (fused AdamW over the flat parameter buffer)"}
         for name, ev in self.rec.items():
@@ -636,6 +655,15 @@ def main():
                                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv["bytes_per_launch"]),
                                "launches": conv["launches"] // 2, "instrumented_passes": 2, "avg_launch_us": round(conv["avg_us"], 1),
                                "algorithmic_gflop_per_launch": round(conv["gflop_per_launch"], 2),
+                               "fused_head_launch": None if not conv.get("fused_head") else {
+                                   "is": "Reconstruction.pre's forward, which since round 4 also evaluates Reconstruction.conv's forward in its epilogue "
+                                         "(tap planes, PSSR_FLAG_HEADQ / PSSR_EPI_HEADQ): head_fwd_kernel's pass over the 1.07 GB tensor (290 us) is gone "
+                                         "from the step, this launch is longer by the plane stores",
+                                   "launches_per_pass": conv["fused_head"]["launches"] // 2, "avg_launch_us": round(conv["fused_head"]["avg_us"], 1),
+                                   "achieved": round(conv["fused_head"]["tflops"], 2),
+                                   "class_without_it": {"achieved": round(conv["fused_head"]["others_tflops"], 2),
+                                                        "frac": round(conv["fused_head"]["others_tflops"] / PEAK_BF16_TFLOPS, 4),
+                                                        "avg_launch_us": round(conv["fused_head"]["others_avg_us"], 1)}},
                                "measured_in": "instrumented eager passes after the timed region: the same kernels one at a time on the launch stream, HIP events "
                                               "(the timed region replays them from a hipGraph with the weight-gradient kernels overlapping on a second stream)"}
         if hbm_objects:

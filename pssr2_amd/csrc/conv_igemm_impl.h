@@ -385,7 +385,8 @@ __device__ __forceinline__ void conv_headq_stage(const ConvArgs& p, float* hq, i
 }
 
 template <typename T, class C>
-__device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], const float* hq, int tid, int x0, int y0, int img0, int n0) {
+__device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&acc)[C::MI][C::NJ], const float* hq, char* smem, int tid, int x0, int y0, int img0,
+                                                    int n0) {
     using X = TT<T>;
     static_assert(sizeof(T) == 2 && C::NJ == 2 && C::MI == 4, "conv_v3 tiles of 128 channels");
     const int lane = tid & 63, wave = tid >> 6;
@@ -411,6 +412,7 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
             wa[nj][ks] = X::pack(wv);
         }
     }
+    float qv[4][5];                                 // per row tile: taps 4 h + 0..3, and (h = 0) tap 8
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         f32x16 q;
@@ -425,25 +427,53 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(acc[mi][nj][8 * ks + i] + bias[nj][8 * ks + i], 0.f);
                 X::mma(q, wa[nj][ks], X::pack(v));
             }
-        const int m = epi_pixel<C>(wm * 32 + r, mi);
-        const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
-        const int gy = y0 + ty, gx = x0 + tx;
-        if (gy < p.H && gx < p.W) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) qv[mi][u] = q[u];
+    }
+    // The waves (wm, 0) and (wm, 1) hold the same 128 pixels for two sub-pixels that are neighbours along x (sub = 2 tn + wn): wave
+    // (wm, 1) hands its products over through LDS (free after the main loop) and wave (wm, 0) stores PAIRS -- 8 bytes per lane and
+    // plane instead of 4 + 4: the 4-byte stores, every lane its own request, were what the fused launch cost (+150 us on c2's pre).
+    float* const xch = (float*)smem;                // [wm][mi][u][64 lanes]
+    static_assert(C::WN == 2, "two sub-pixels per workgroup");
+    if (wn == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) xch[((wm * 4 + mi) * 5 + u) * 64 + lane] = qv[mi][u];
+    }
+    __syncthreads();
+    if (wn == 0) {
+        const int HH = 4 * p.H, WW = 4 * p.W;
+        float* const qb = p.head_q + (long)img0 * HH * WW;
+        const long plane = (long)p.N * HH * WW;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = epi_pixel<C>(wm * 32 + r, mi);
+            const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
+            const int gy = y0 + ty, gx = x0 + tx;
+            if (!(gy < p.H && gx < p.W)) continue;
             // the product of tap (ky, kx) at high-resolution pixel P' belongs to output pixel P' - (ky - 1, kx - 1): stored there, in
             // the tap's own plane, the nine planes add up position by position (no halo, no shuffle in the gather)
-            const int HH = 4 * p.H, WW = 4 * p.W;
-            const int Y0 = 4 * gy + (sub >> 2), X0 = 4 * gx + (sub & 3);
-            float* const qb = p.head_q + (long)img0 * HH * WW;
-            const long plane = (long)p.N * HH * WW;
+            const int Y0 = 4 * gy + (sub >> 2), X0 = 4 * gx + (sub & 3);           // sub & 3 is even here: this wave's pixel and its right neighbour
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
                 if (u == 4 && h) continue;
                 const int tap = u == 4 ? 8 : 4 * h + u;
                 const int Y = Y0 - (tap / 3 - 1), Xp = X0 - (tap % 3 - 1);
-                if (Y >= 0 && Y < HH && Xp >= 0 && Xp < WW) qb[tap * plane + (long)Y * WW + Xp] = q[u];
+                if (Y < 0 || Y >= HH) continue;
+                float* const d = qb + tap * plane + (long)Y * WW + Xp;
+                const float mine = qv[mi][u], other = xch[((wm * 4 + mi) * 5 + u) * 64 + lane];
+                if (Xp >= 0 && Xp + 1 < WW) {
+                    typedef float f2_t __attribute__((ext_vector_type(2), aligned(4)));
+                    *(f2_t*)d = f2_t{mine, other};
+                } else {
+                    if (Xp >= 0 && Xp < WW) d[0] = mine;
+                    if (Xp + 1 >= 0 && Xp + 1 < WW) d[1] = other;
+                }
             }
         }
     }
+    if (p.epi != PSSR_EPI_HEADQ) __syncthreads();      // FLAG_HEADQ: the store epilogue that follows writes its rows over the exchange area
 }
 
 // picks the straight-line 8-channel epilogue when the layout allows (p.epi8, set by the host), else the generic one

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_v3_kernel(const ConvArgs p) {
     }
     if constexpr (BN == 128) {
         if (p.epi == PSSR_EPI_HEADQ || (p.flags & PSSR_FLAG_HEADQ)) {
-            conv_headq_epilogue<T, C>(p, acc, (const float*)(smem + C::LDS_BYTES), tid, x0, y0, img0, n0);
+            conv_headq_epilogue<T, C>(p, acc, (const float*)(smem + C::LDS_BYTES), smem, tid, x0, y0, img0, n0);
             if (p.epi == PSSR_EPI_HEADQ) return;          // FLAG_HEADQ (training): the activation is stored as well
         }
     }
