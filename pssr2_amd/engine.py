@@ -649,6 +649,21 @@ class Engine:
             fn()
         self._fwd_side = True
 
+    def _folded_last(self, module, st, conv, code):
+        """(packed weight, bias) of a block's last convolution with its eval-mode BatchNorm folded in: W' = W * scale[co],
+        b' = conv.bias * scale + shift + respass.bias.  Cached per (parameter versions, BatchNorm affine)."""
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        rp = module.respass
+        key = (self._wepoch[0], conv.weight._version, conv.bias._version, rp.bias._version, st.eval_key, code)
+        ent = cache.get(id(conv))
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                wf = (conv.weight.detach() * st.scale.view(-1, 1, 1, 1)).contiguous()
+                bf = torch.addcmul(st.shift, conv.bias.detach(), st.scale).add_(rp.bias.detach())
+            pw = ops.pack_conv_weight(wf, code, mode=0, out=ent[1] if ent is not None else None)
+            ent = cache[id(conv)] = (key, pw, bf)
+        return ent[1], ent[2]
+
     def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
         if getattr(blk, "a", None) is not None:          # ResBlockA (pssr2_amd/atrous.py); a first block reads the plain input
             from . import atrous as A
@@ -671,12 +686,28 @@ class Engine:
                 else:
                     spec = dict(fwd=dict(mode=0), dgrad=dict(mode=1))
                     inp, icn = blk.y[k - 1], blk.c
-                pw = self._conv(conv, **spec).get("fwd", p.code)
                 if k < nl - 1:
+                    pw = self._conv(conv, **spec).get("fwd", p.code)
                     ops.conv2d(inp, icn, pw, blk.y[k], blk.c, n=n, h=hh, w=ww, bias=conv.bias, flags=L.FLAG_RELU | L.FLAG_AFFINE,
                                aux_scale=blk.bn[k].scale, aux_shift=blk.bn[k].shift)
+                    continue
+                # the last convolution takes the residual 1x1 (module.respass on the block input) as its second source and ends in
+                # the block's ReLU: out = relu(bn(conv(a)) + respass(src)) with the BatchNorm's scale folded into THIS convolution's
+                # weight rows (exact in eval mode; no division by a scale that may be zero) -- the raw map y[-1] is never stored and
+                # the separate tail launch (a pass over src, y[-1] and the output) is gone
+                rp = module.respass
+                if first:
+                    pwr = self._conv(rp, fwd=dict(mode=2, center=True), dgrad=dict(mode=3, center=True)).get("fwd", p.code)
                 else:
-                    ops.conv2d(inp, icn, pw, blk.y[k], blk.c, n=n, h=hh, w=ww, bias=conv.bias)
+                    pwr = self._conv(rp, fwd=dict(mode=0), dgrad=dict(mode=1)).get("fwd", p.code)
+                if spec["fwd"]["mode"] == 0:
+                    pwf, bf = self._folded_last(module, blk.bn[k], conv, p.code)
+                    ops.conv2d(inp, icn, pwf, dst, blk.c, n=n, h=hh, w=ww, out_coff=dst_coff, bias=bf, x1=src, cin1=cin, w1=pwr,
+                               flags=L.FLAG_RELU)
+                    return
+                # (a block of ONE convolution on the network input: both sources are flat-K 1x1 forms -- keep the separate tail)
+                pw = self._conv(conv, **spec).get("fwd", p.code)
+                ops.conv2d(inp, icn, pw, blk.y[k], blk.c, n=n, h=hh, w=ww, bias=conv.bias)
             nl = 0          # (the loop below is the training / f32 form)
         for k in range(nl):
             conv = module.conv[3 * k]

@@ -453,3 +453,33 @@ def test_eval_batchnorm_in_the_producing_epilogue(golden, monkeypatch, dt):
     assert not torch.equal(outs["pro"], outs["epi"])            # the two forms really are different code paths
     assert e_epi <= 1.25 * e_pro + 1e-3 * scale, (e_epi, e_pro)
     assert abs(_psnr(outs["epi"], outs["f32"]) - _psnr(outs["pro"], outs["f32"])) < 6.0
+
+
+@pytest.mark.parametrize("depth,hidden", [(0, [16, 32]), (1, [32, 64, 128]), (3, [16, 32])])
+def test_eval_block_with_the_tail_in_the_last_convolution(monkeypatch, depth, hidden):
+    """Round 4 (eval mode, 16-bit storage): a block's last convolution carries the residual 1x1 as its second source, the BatchNorm folded into
+    its weight rows and the block's ReLU -- no tail launch, the raw last map is never stored.  Against the training-style eval forward
+    (PSSR_EVAL_AFFINE=0: prologues + tail launch) and the exact-f32 engine, with non-trivial BatchNorm statistics."""
+    import pssr2_amd.engine as E
+    from pssr2_amd.models import ResUNet
+    torch.manual_seed(depth + 3)
+    x = (torch.rand(2, 1, 32, 32) * 255).cuda()
+    ref = ResUNet(hidden=hidden, depth=depth).cuda()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(-1.2, 1.5); m.bias.normal_(0, 0.3)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    outs = {}
+    for name, aff, dt in (("f32", False, torch.float32), ("old", False, torch.float16), ("new", True, torch.float16)):
+        monkeypatch.setattr(E, "_EVAL_AFFINE", aff)
+        model = ResUNet(hidden=hidden, depth=depth).cuda().eval()
+        model.load_state_dict(sd)
+        model.compute_dtype = dt
+        model.infer_dtype = dt
+        with torch.no_grad():
+            outs[name] = model(x).float().clone()
+    scale = float(outs["f32"].abs().max())
+    e_old, e_new = float((outs["old"] - outs["f32"]).abs().max()), float((outs["new"] - outs["f32"]).abs().max())
+    assert torch.isfinite(outs["new"]).all() and not torch.equal(outs["new"], outs["old"])
+    assert e_new <= 1.5 * e_old + 2e-3 * scale, (e_new, e_old, scale)
