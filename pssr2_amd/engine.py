@@ -661,6 +661,8 @@ class Engine:
                 wf = (conv.weight.detach() * st.scale.view(-1, 1, 1, 1)).contiguous()
                 bf = torch.addcmul(st.shift, conv.bias.detach(), st.scale).add_(rp.bias.detach())
             pw = ops.pack_conv_weight(wf, code, mode=0, out=ent[1] if ent is not None else None)
+            if ent is not None:                 # in place: a captured eval graph (fastpath.EvalStepper) holds these two buffers by address
+                bf = ent[2].copy_(bf)
             ent = cache[id(conv)] = (key, pw, bf)
         return ent[1], ent[2]
 
