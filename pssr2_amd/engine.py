@@ -654,8 +654,8 @@ class Engine:
         b' = conv.bias * scale + shift + respass.bias.  Cached per (parameter versions, BatchNorm affine)."""
         cache = self.__dict__.setdefault("_fold_cache", {})
         rp = module.respass
-        key = (self._wepoch[0], conv.weight._version, conv.bias._version, rp.bias._version, st.eval_key, code)
-        ent = cache.get(id(conv))
+        key = (self._wepoch[0], conv.weight._version, conv.bias._version, rp.bias._version, st.eval_key)
+        ent = cache.get((id(conv), code))
         if ent is None or ent[0] != key:
             with torch.no_grad():
                 wf = (conv.weight.detach() * st.scale.view(-1, 1, 1, 1)).contiguous()
@@ -663,7 +663,7 @@ class Engine:
             pw = ops.pack_conv_weight(wf, code, mode=0, out=ent[1] if ent is not None else None)
             if ent is not None:                 # in place: a captured eval graph (fastpath.EvalStepper) holds these two buffers by address
                 bf = ent[2].copy_(bf)
-            ent = cache[id(conv)] = (key, pw, bf)
+            ent = cache[(id(conv), code)] = (key, pw, bf)
         return ent[1], ent[2]
 
     def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
