@@ -208,7 +208,7 @@ class HbmTimer:
         bwd_b = lambda g, gs, wt, act, dact, blk, dwr, br, n, h, w, cin, cout, dt: n * h * w * (2 * cin * esz(dt) + 4 * cout)
         adam_b = lambda p, *a, **kw: 28 * p.numel()
         # head_q_gather(q, bias, out, n, hh, ww, scale, shift): nine f32 planes read, the f32 image written
-        gat_b = lambda q, b, out, n, hh, ww, *a, **kw: 40 * n * hh * ww
+        gat_b = lambda q, b, out, n, h, w, *a, **kw: 40 * n * h * w * 16
         for name, nb in (("head_conv_fwd", fwd_b), ("head_q_gather", gat_b), ("head_conv_bwd_rows", bwd_b), ("adamw_step_dev", adam_b), ("adamw_step", adam_b)):
             self.orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self.orig[name], nb))

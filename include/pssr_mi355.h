@@ -91,10 +91,10 @@ enum {
     PSSR_EPI_DGRAD_MASK = 2, /* out = (aux*aux_scale+aux_shift > 0) ? acc : 0   (ReLU backward) */
     PSSR_EPI_DGRAD_GELU = 4, /* out = acc * gelu'(aux)   (GELU backward; with FLAG_STATS stats[0..cout) += sum out)  */
     PSSR_EPI_HEADQ = 5,      /* inference form of Reconstruction (_blocks.py:15-18) for 64 hidden channels and ONE output channel: the
-                              * epilogue of `pre` (FLAG_RELU implied, channels sub-pixel major, cout = r*r*64) does not store its
-                              * activation but the nine per-tap dot products of relu(acc + bias) with Reconstruction.conv's weights,
-                              * each at the output position it contributes to: head_q[tap][n][r h][r w] (f32, positions no product
-                              * reaches stay as the caller zeroed them once); pssr_head_q_gather adds the nine planes.
+                              * epilogue of `pre` (FLAG_RELU implied, channels sub-pixel major, cout = 16 * 64) does not store its
+                              * activation but the nine per-tap dot products of relu(acc + bias) with Reconstruction.conv's weights:
+                              * head_q[tap][sub][n][h][w] (f32) for sub-pixel sub of low-resolution pixel (n, y, x);
+                              * pssr_head_q_gather sums, for every output pixel, the nine products of its shifted neighbours.
                               * 16-bit storage, the conv_v3 tiles (h, w >= 16); PSSR_ERR_UNSUPPORTED otherwise */
     PSSR_EPI_FINAL = 3       /* out_f32_nchw = (acc + bias)*out_scale + out_shift; any cout <= 32
                                 (Reconstruction.conv + "x*128+128", _blocks.py:17, resunet.py:95)  */
@@ -150,7 +150,7 @@ typedef struct pssr_conv_desc {
      * uninitialised, caller-owned; NULL (or too small) simply disables the split                                   */
     void* workspace; int64_t workspace_bytes;
     /* EPI_HEADQ only (appended in ABI version 3; other epilogues never read them): Reconstruction.conv's weight [1][64][3][3] f32 and
-     * the nine tap-product planes [9][n][r h][r w] f32 (r * r = cout / 64), zeroed once by the caller */
+     * the tap products [9][16][n][h][w] f32 */
     const float* head_w; float* head_q;
 } pssr_conv_desc;
 
@@ -527,10 +527,11 @@ int pssr_ese_bwd(const float* A, const float* gate, const float* u, const float*
                  const float* w_fc, int n, int c, int hw, float* du, float* dgamma, float* db_fc, float* dw_fc, float* add,
                  pssr_stream_t stream);
 
-/* Second half of the inference form (PSSR_EPI_HEADQ): out_f32_nchw[n][0][Y][X] = (bias + sum of the nine tap planes at (n, Y, X)) *
- * out_scale + out_shift  (F.pixel_shuffle + Reconstruction.conv, _blocks.py:17; "x * 128 + 128", resunet.py:94).  hh, ww: the
- * high-resolution size; ww a multiple of 4. */
-int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int hh, int ww,
+/* Second half of PSSR_EPI_HEADQ / PSSR_FLAG_HEADQ: out_f32_nchw[n][0][Y][X] = (bias + sum over the 9 taps (ky, kx) of
+ * q[tap] at high-resolution pixel (Y + ky - 1, X + kx - 1), zero outside the image) * out_scale + out_shift, high-resolution pixel
+ * (4 y + i, 4 x + j) being sub-pixel 4 i + j of low-resolution pixel (y, x)  (F.pixel_shuffle + Reconstruction.conv, _blocks.py:17;
+ * "x * 128 + 128", resunet.py:94).  h, w: the LOW-resolution size. */
+int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int h, int w,
                        float out_scale, float out_shift, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -373,9 +373,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
 // the k slots 8 (lane >> 5) + i when element e = 8 ks + i of tile nj is taken as slot i of k-step (nj, ks).  So relu(acc + bias) is
 // rounded to the storage type (exactly the value the store would have written), packed in place, and four MFMAs per row tile against
 // the head weights arranged in the matching slot order (A operand: row = tap) leave q[tap][pixel] = sum over the wave's 64 channels
-// = one sub-pixel: rows 0-3 and 8 with lanes 0-31, rows 4-7 with lanes 32-63.  36 bytes per high-resolution pixel leave instead of 128,
-// as nine 4-byte stores into the tap planes (16 lanes of a row = every fourth float of 256 bytes; the other three come from the waves
-// and workgroups that own the neighbouring sub-pixels and meet them in the XCD's L2).
+// = one sub-pixel: rows 0-3 and 8 with lanes 0-31, rows 4-7 with lanes 32-63.  36 bytes per high-resolution pixel leave instead of 128.
 // (`hq`: [0, 576) Reconstruction.conv's weights [c][tap], [576, 704) pre's bias of the workgroup's 128 channels -- staged in LDS by
 // conv_headq_stage at kernel entry: fetched here, 64 dependent-latency loads per lane stood in front of every workgroup's epilogue)
 constexpr int HEADQ_LDS = (64 * 9 + 128) * 4;
@@ -412,7 +410,11 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
             wa[nj][ks] = X::pack(wv);
         }
     }
-    float qv[4][5];                                 // per row tile: taps 4 h + 0..3, and (h = 0) tap 8
+    // Every product goes to the plane of its (tap, sub-pixel) at LOW resolution, head_q[tap][sub][n][h][w]: the 16 lanes that hold one
+    // image row of the tile write 64 contiguous bytes.  (The first versions stored at the high-resolution output position -- every
+    // lane its own 4- or 8-byte piece of a different 32-byte sector: +150 us on c2's `pre`, an L2 write transaction per piece.)
+    const long lrplane = (long)p.N * p.H * p.W;
+    float* const qsub = p.head_q + (long)sub * lrplane + (long)img0 * p.H * p.W;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         f32x16 q;
@@ -427,53 +429,17 @@ __device__ __forceinline__ void conv_headq_epilogue(const ConvArgs& p, f32x16 (&
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(acc[mi][nj][8 * ks + i] + bias[nj][8 * ks + i], 0.f);
                 X::mma(q, wa[nj][ks], X::pack(v));
             }
+        const int m = epi_pixel<C>(wm * 32 + r, mi);
+        const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
+        const int gy = y0 + ty, gx = x0 + tx;
+        if (gy < p.H && gx < p.W) {
+            float* const d = qsub + (long)gy * p.W + gx;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) qv[mi][u] = q[u];
-    }
-    // The waves (wm, 0) and (wm, 1) hold the same 128 pixels for two sub-pixels that are neighbours along x (sub = 2 tn + wn): wave
-    // (wm, 1) hands its products over through LDS (free after the main loop) and wave (wm, 0) stores PAIRS -- 8 bytes per lane and
-    // plane instead of 4 + 4: the 4-byte stores, every lane its own request, were what the fused launch cost (+150 us on c2's pre).
-    float* const xch = (float*)smem;                // [wm][mi][u][64 lanes]
-    static_assert(C::WN == 2, "two sub-pixels per workgroup");
-    if (wn == 1) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int u = 0; u < 5; ++u) xch[((wm * 4 + mi) * 5 + u) * 64 + lane] = qv[mi][u];
-    }
-    __syncthreads();
-    if (wn == 0) {
-        const int HH = 4 * p.H, WW = 4 * p.W;
-        float* const qb = p.head_q + (long)img0 * HH * WW;
-        const long plane = (long)p.N * HH * WW;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = epi_pixel<C>(wm * 32 + r, mi);
-            const int tx = m & (C::TW - 1), ty = (m >> C::TWL) & (C::TH - 1);
-            const int gy = y0 + ty, gx = x0 + tx;
-            if (!(gy < p.H && gx < p.W)) continue;
-            // the product of tap (ky, kx) at high-resolution pixel P' belongs to output pixel P' - (ky - 1, kx - 1): stored there, in
-            // the tap's own plane, the nine planes add up position by position (no halo, no shuffle in the gather)
-            const int Y0 = 4 * gy + (sub >> 2), X0 = 4 * gx + (sub & 3);           // sub & 3 is even here: this wave's pixel and its right neighbour
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                if (u == 4 && h) continue;
-                const int tap = u == 4 ? 8 : 4 * h + u;
-                const int Y = Y0 - (tap / 3 - 1), Xp = X0 - (tap % 3 - 1);
-                if (Y < 0 || Y >= HH) continue;
-                float* const d = qb + tap * plane + (long)Y * WW + Xp;
-                const float mine = qv[mi][u], other = xch[((wm * 4 + mi) * 5 + u) * 64 + lane];
-                if (Xp >= 0 && Xp + 1 < WW) {
-                    typedef float f2_t __attribute__((ext_vector_type(2), aligned(4)));
-                    *(f2_t*)d = f2_t{mine, other};
-                } else {
-                    if (Xp >= 0 && Xp < WW) d[0] = mine;
-                    if (Xp + 1 >= 0 && Xp + 1 < WW) d[1] = other;
-                }
-            }
+            for (int u = 0; u < 4; ++u) d[(long)(4 * h + u) * 16 * lrplane] = q[u];
+            if (h == 0) d[(long)8 * 16 * lrplane] = q[4];
         }
     }
-    if (p.epi != PSSR_EPI_HEADQ) __syncthreads();      // FLAG_HEADQ: the store epilogue that follows writes its rows over the exchange area
+    (void)smem;
 }
 
 // picks the straight-line 8-channel epilogue when the layout allows (p.epi8, set by the host), else the generic one

@@ -134,21 +134,42 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ inference: sum of the tap planes
-// Second half of PSSR_EPI_HEADQ (conv_igemm_impl.h: conv_headq_epilogue stores every tap product at the output position it belongs
-// to): out = (bias + sum of the nine planes) * scale + shift, four outputs (one float4 of each plane) per thread.
+// ------------------------------------------------------------------------------------------------ sum of the tap products
+// Second half of PSSR_EPI_HEADQ / PSSR_FLAG_HEADQ (conv_igemm_impl.h: conv_headq_epilogue): q[tap][sub][n][h][w] holds, for the
+// high-resolution pixel (4 y + i, 4 x + j) = (low-resolution pixel (y, x), sub-pixel sub = 4 i + j), its product with tap (ky, kx) of
+// Reconstruction.conv.  out[P] = bias + sum_tap q[tap][P + (ky - 1, kx - 1)] (zero outside the image).  A thread makes the four outputs
+// (4 y + i, 4 x .. 4 x + 3) of one low-resolution pixel row position; lanes walk x, so each of its 36 reads is a unit-stride wave access
+// into one (tap, sub-pixel) plane and the store is one float4.
 __global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restrict__ q, const float* __restrict__ bias, float* __restrict__ out,
-                                                            long total4, long plane4, float out_scale, float out_shift) {
+                                                            int n, int h, int w, float out_scale, float out_shift) {
+    const long lrplane = (long)n * h * w;
     const float b = bias ? bias[0] : 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        float4 s = make_float4(b, b, b, b);
+    const long total = lrplane * 4;                     // (image, y, i, x)
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(t % w);
+        long r = t / w;
+        const int i = (int)(r & 3); r >>= 2;
+        const int y = (int)(r % h);
+        const long img = r / h;
+        float s[4] = {b, b, b, b};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float4 v = ((const float4*)q)[t * plane4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int Y = 4 * y + i + ky - 1;
+            if (Y < 0 || Y >= 4 * h) continue;
+            const int yy = Y >> 2, ii = Y & 3;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* const qt = q + ((long)(ky * 3 + kx) * 16 + ii * 4) * lrplane + (img * h + yy) * (long)w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int X = 4 * x + j + kx - 1;           // = 4 xx + jj
+                    if (X < 0 || X >= 4 * w) continue;
+                    s[j] += qt[(long)(X & 3) * lrplane + (X >> 2)];
+                }
+            }
         }
-        ((float4*)out)[i] = make_float4(fmaf(s.x, out_scale, out_shift), fmaf(s.y, out_scale, out_shift), fmaf(s.z, out_scale, out_shift),
-                                        fmaf(s.w, out_scale, out_shift));
+        *(float4*)(out + ((img * h + y) * 4 + i) * (4L * w) + 4 * x) =
+            make_float4(fmaf(s[0], out_scale, out_shift), fmaf(s[1], out_scale, out_shift), fmaf(s[2], out_scale, out_shift), fmaf(s[3], out_scale, out_shift));
     }
 }
 
@@ -647,13 +668,13 @@ int pssr_head_conv_fwd(const void* in, int in_cs, int in_co, int in_blk, const f
     return PSSR_OK;
 }
 
-int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int hh, int ww, float out_scale, float out_shift,
+int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int h, int w, float out_scale, float out_shift,
                        pssr_stream_t s) {
-    PSSR_CHECK(q && out_nchw && n > 0 && hh > 0 && ww > 0 && ww % 4 == 0, PSSR_ERR_ARG, "head_q_gather: bad args");
-    const long total4 = (long)n * hh * ww / 4;
-    const long blocks = (total4 + 255) / 256;
-    hipLaunchKernelGGL(head_q_gather_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)s, q, bias, out_nchw, total4,
-                       total4, out_scale, out_shift);
+    PSSR_CHECK(q && out_nchw && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "head_q_gather: bad args");
+    const long total = (long)n * h * w * 4;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(head_q_gather_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)s, q, bias, out_nchw, n, h, w,
+                       out_scale, out_shift);
     PSSR_LAUNCH_CHECK();
     return PSSR_OK;
 }

@@ -803,8 +803,9 @@ class Engine:
     def _head_forward(self, p, feat, x, train=True):
         """relu(conv3x3([feat | x0])) in sub-pixel-major channel order (== pixel-shuffled, blocked layout) -> conv3x3 ->
         x*128+128 (pssr/models/_blocks.py:15-18, pssr/models/resunet.py:90-95).  With 64 hidden channels, one output channel and 16-bit
-        storage `pre`'s epilogue multiplies its activation with the final convolution's taps in registers (each product stored at the
-        output position it belongs to, in its tap's plane) and a second kernel adds the nine planes: Reconstruction.conv never reads the
+        storage `pre`'s epilogue multiplies its activation with the final convolution's taps in registers (nine products per high-resolution
+        pixel, stored in per-(tap, sub-pixel) planes at low resolution) and a second kernel sums the nine shifted products of every output
+        pixel: Reconstruction.conv never reads the
         64-channel high-resolution tensor (1.07 GB at batch 32), and in eval mode -- nothing is kept for a backward pass -- that tensor
         is not written either."""
         rec = self.model.reconstruction
@@ -818,16 +819,14 @@ class Engine:
         out = torch.empty(n, self.cout, h * r, w * r, dtype=torch.float32, device=x.device)
         if _HEAD_FUSE and ops.head_q_supported(code, h0, self.cout, r, h, w):
             if getattr(p, "head_q", None) is None:
-                # nine tap planes at the output resolution; positions no product reaches (where a tap would read the zero padding) keep
-                # the zeros of this allocation for good
-                p.head_q = torch.zeros(9, n, h * r, w * r, dtype=torch.float32, device=x.device)
+                p.head_q = torch.empty(9, r * r, n, h, w, dtype=torch.float32, device=x.device)     # [tap][sub-pixel] planes of tap products
             if train:       # the activation is kept for the backward pass (FLAG_HEADQ: stored AND multiplied with the head's taps)
                 ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias, x1=p.xcol, cin1=self.xc,
                            w1=cpre.get("fwd1", code), flags=L.FLAG_RELU | L.FLAG_HEADQ, head_w=rec.conv.weight, head_q=p.head_q)
             else:
                 ops.conv2d(feat, h0, cpre.get("fwd0", code), p.head_q, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias, x1=p.xcol, cin1=self.xc,
                            w1=cpre.get("fwd1", code), epilogue=L.EPI_HEADQ, head_w=rec.conv.weight, head_q=p.head_q)
-            ops.head_q_gather(p.head_q, rec.conv.bias, out, n, h * r, w * r, 128.0, 128.0)
+            ops.head_q_gather(p.head_q, rec.conv.bias, out, n, h, w, 128.0, 128.0)
             return out
         ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias,
                    x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)

@@ -61,7 +61,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
            aux=None, aux_coff=0, aux_scale=None, aux_shift=None, aux_mean=None, aux_invstd=None, stats=None,
            in0_blk=0, out_blk=0, aux_blk=0, out_scale=1.0, out_shift=0.0, gelu_in=False, head_w=None, head_q=None):
     """x/out/aux: NHWC tensors [n, h, w, cstride] in the compute dtype (channel slices via *_coff).  EPI_HEADQ: ``out`` is unused (pass
-    ``head_q``), the tap products go to the nine planes ``head_q`` [9, n, 4h, 4w] f32 (zeroed once by the caller)."""
+    ``head_q``), the tap products go to ``head_q`` [9, 16, n, h, w] f32."""
     d = L.ConvDesc()
     d.dtype = w0.dtype
     d.n, d.h, d.w = n, h, w
@@ -537,8 +537,8 @@ def head_q_supported(dtype, h0, cout, r, h, w):
     return dtype != L.F32 and h0 == 64 and cout == 1 and r == 4 and h >= 16 and w >= 16 and L.lib().pssr_get_option(b"IGEMM_V3") > 0
 
 
-def head_q_gather(q, bias, out, n, hh, ww, out_scale, out_shift):
-    L.check(L.lib().pssr_head_q_gather(L.ptr(q), L.ptr(bias), L.ptr(out), n, hh, ww, C.c_float(out_scale), C.c_float(out_shift), L.stream_ptr()),
+def head_q_gather(q, bias, out, n, h, w, out_scale, out_shift):
+    L.check(L.lib().pssr_head_q_gather(L.ptr(q), L.ptr(bias), L.ptr(out), n, h, w, C.c_float(out_scale), C.c_float(out_shift), L.stream_ptr()),
             "pssr_head_q_gather")
 
 
