@@ -83,9 +83,9 @@ def test_c1_training_step_loss_and_every_gradient_vs_oracle(capsys):
     assert not bad, bad
 
 
-def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
-    """pssr/train.py:94-103 for three steps (forward, loss of (hr_hat / 255, hr / 255), backward, AdamW step, zero_grad) on 4 fixed
-    pairs: HIP f32 through pssr2_amd.train.train_paired against the same loop on the CPU oracle (torch fp32 autograd + torch AdamW)."""
+def _c1_three_steps(make_opt):
+    """pssr/train.py:94-103 for three steps on 4 fixed pairs, HIP f32 through pssr2_amd.train.train_paired and the same loop on the CPU oracle
+    (torch fp32 autograd), both with the optimizer ``make_opt(params)`` builds.  Returns (losses, oracle losses, weight deviation ratio)."""
     from oracle import loss_ref, model_ref as M
     from pssr2_amd.models import ResUNet
     from pssr2_amd.train import train_paired
@@ -107,14 +107,14 @@ def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
         def __getitem__(self, i):
             return hr_c[i], lr_c[i]
 
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = make_opt(model.parameters())
     random.seed(3)
     tl, vl = train_paired(model, DS(), 4, SSIMLoss(mix=0.8), opt, epochs=3, device="cuda", log_frequency=1)
     assert len(tl) == 3 and len(vl) == 3
     # ---- the oracle loop: every epoch is ONE batch of the same four pairs (their order inside the batch does not matter)
     params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd0.items()}
     names = [n for n, _ in model.named_parameters()]
-    opt_ref = torch.optim.AdamW([params[n] for n in names], lr=1e-3)
+    opt_ref = make_opt([params[n] for n in names])
     ref_losses = []
     for _ in range(3):
         yr, new_stats = M.resunet_forward(lr_c[:4], params, 5, 3, 4, train=True)
@@ -123,7 +123,6 @@ def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
         opt_ref.step()
         opt_ref.zero_grad()
         ref_losses.append(lo.item())
-    rel = [abs(a - b) / abs(b) for a, b in zip(tl, ref_losses)]
     sd1 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     moved, dev = [], []
     for n in names:
@@ -132,7 +131,13 @@ def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
             continue        # exact-zero gradient in front of BatchNorm: autograd's round-off there becomes a full Adam step (tests/test_gpu_fastpath.py)
         moved.append(float((params[n].detach() - sd0[n]).abs().mean()))
         dev.append(float((sd1[n] - params[n].detach()).abs().mean()))
-    ratio = sum(dev) / sum(moved)
+    return tl, ref_losses, sum(dev) / sum(moved)
+
+
+def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
+    """The c1 defaults: torch AdamW(lr 1e-3, eps 1e-8)."""
+    tl, ref_losses, ratio = _c1_three_steps(lambda ps: torch.optim.AdamW(ps, lr=1e-3))
+    rel = [abs(a - b) / abs(b) for a, b in zip(tl, ref_losses)]
     with capsys.disabled():
         print(f"\n[c1 train_paired] losses HIP {np.round(tl, 6)} oracle {np.round(ref_losses, 6)} (rel {np.array(rel)}); "
               f"mean |w_HIP - w_oracle| / mean |w_oracle - w_0| after 3 AdamW steps = {ratio:.2e}")
@@ -141,3 +146,16 @@ def test_c1_train_paired_three_steps_vs_oracle_loop(capsys):
     # GPU, so ~5 % of the weights differ by 2 lr after three steps (measured ratio 0.11) while the losses stay within 7e-4
     assert rel[0] <= 1e-5 and max(rel) <= 2e-3
     assert ratio <= 0.2
+
+
+def test_c1_train_paired_three_sgd_steps_vs_oracle_loop(capsys):
+    """the same three steps with an optimizer whose update is LINEAR in the gradient (SGD with momentum), so that a
+    gradient within round-off of zero moves its weight by round-off, not by +-lr: the weights of the two loops then agree to the
+    gradients' own agreement (9e-5 of their maximum, test above) and the bar is two orders of magnitude tighter than AdamW's."""
+    tl, ref_losses, ratio = _c1_three_steps(lambda ps: torch.optim.SGD(ps, lr=0.02, momentum=0.9))
+    rel = [abs(a - b) / abs(b) for a, b in zip(tl, ref_losses)]
+    with capsys.disabled():
+        print(f"\n[c1 train_paired, SGD] losses HIP {np.round(tl, 6)} oracle {np.round(ref_losses, 6)} (rel {np.array(rel)}); "
+              f"mean |w_HIP - w_oracle| / mean |w_oracle - w_0| after 3 SGD steps = {ratio:.2e}")
+    assert rel[0] <= 1e-5 and max(rel) <= 1e-4
+    assert ratio <= 2e-3
