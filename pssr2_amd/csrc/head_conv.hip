@@ -173,6 +173,60 @@ __global__ __launch_bounds__(256) void head_q_gather_kernel(const float* __restr
     }
 }
 
+// The same sums for widths that are multiples of 4 (every tile size the drivers use): a thread makes the 16 outputs (4 y + i, 16 x4 .. 16 x4 + 15)
+// from 36 16-byte loads (a (tap, sub-pixel) plane row at 4 x4 .. 4 x4 + 3; the six planes that feed from the neighbouring low-resolution
+// column add one 4-byte load each) and stores 64 contiguous bytes.  4-byte loads stream at 3.5 TB/s here, 16-byte ones at the rate of a copy.
+// Per output the order of the nine additions is that of the kernel above: the two are bit-identical.
+__global__ __launch_bounds__(256) void head_q_gather4_kernel(const float* __restrict__ q, const float* __restrict__ bias, float* __restrict__ out,
+                                                             int n, int h, int w, float out_scale, float out_shift) {
+    const long lrplane = (long)n * h * w;
+    const int w4 = w >> 2;
+    const float b = bias ? bias[0] : 0.f;
+    const long total = (long)n * h * 4 * w4;            // (image, y, i, x4)
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(t % w4);
+        long r = t / w4;
+        const int i = (int)(r & 3); r >>= 2;
+        const int y = (int)(r % h);
+        const long img = r / h;
+        float s[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[a][j] = b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int Y = 4 * y + i + ky - 1;
+            if (Y < 0 || Y >= 4 * h) continue;
+            const int yy = Y >> 2, ii = Y & 3;
+            const float* const row = q + ((long)(ky * 3) * 16 + ii * 4) * lrplane + (img * h + yy) * (long)w + 4 * x4;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = j + kx - 1;                   // high-resolution column 4 x + d of low-resolution column x
+                    const float* const pl = row + ((long)kx * 16 + (d & 3)) * lrplane;
+                    const float4 v = *(const float4*)pl;
+                    if (d < 0) {
+                        const float prev = x4 > 0 ? pl[-1] : 0.f;
+                        s[0][j] += prev; s[1][j] += v.x; s[2][j] += v.y; s[3][j] += v.z;
+                    } else if (d > 3) {
+                        const float next = x4 < w4 - 1 ? pl[4] : 0.f;
+                        s[0][j] += v.y; s[1][j] += v.z; s[2][j] += v.w; s[3][j] += next;
+                    } else {
+                        s[0][j] += v.x; s[1][j] += v.y; s[2][j] += v.z; s[3][j] += v.w;
+                    }
+                }
+            }
+        }
+        float* const o = out + ((img * h + y) * 4 + i) * (4L * w) + 16 * x4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            *(float4*)(o + 4 * a) = make_float4(fmaf(s[a][0], out_scale, out_shift), fmaf(s[a][1], out_scale, out_shift),
+                                                fmaf(s[a][2], out_scale, out_shift), fmaf(s[a][3], out_scale, out_shift));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dgrad (+ ReLU mask)
 template <typename H, int NT>     // NT = cin/16 output-channel tiles; cout*9 <= 32 (one K step)
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadArgs p) {
@@ -671,6 +725,13 @@ int pssr_head_conv_fwd(const void* in, int in_cs, int in_co, int in_blk, const f
 int pssr_head_q_gather(const float* q, const float* bias, float* out_nchw, int n, int h, int w, float out_scale, float out_shift,
                        pssr_stream_t s) {
     PSSR_CHECK(q && out_nchw && n > 0 && h > 0 && w > 0, PSSR_ERR_ARG, "head_q_gather: bad args");
+    if (w % 4 == 0 && ((uintptr_t)q | (uintptr_t)out_nchw) % 16 == 0) {
+        const long blocks4 = ((long)n * h * w + 255) / 256;
+        hipLaunchKernelGGL(head_q_gather4_kernel, dim3((unsigned)(blocks4 < 16384 ? blocks4 : 16384)), dim3(256), 0, (hipStream_t)s, q, bias, out_nchw,
+                           n, h, w, out_scale, out_shift);
+        PSSR_LAUNCH_CHECK();
+        return PSSR_OK;
+    }
     const long total = (long)n * h * w * 4;
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(head_q_gather_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)s, q, bias, out_nchw, n, h, w,

@@ -122,3 +122,24 @@ def test_training_head_keeps_the_activation_and_the_tap_planes(monkeypatch):
     for n in ga:
         scale = float(gb[n].abs().max()) + 1e-12
         assert float((ga[n] - gb[n]).abs().max()) <= 2e-2 * scale, n
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 20), (3, 17, 18), (1, 16, 16), (2, 5, 128)])
+def test_head_q_gather_sums_the_shifted_tap_planes(shape):
+    """pssr_head_q_gather alone, both kernels (widths that are / are not multiples of 4): out[P] = bias + sum over the nine taps of the
+    plane value at P + (ky - 1, kx - 1), zero outside the image, against the same sum in float64."""
+    from pssr2_amd import ops
+    n, h, w = shape
+    torch.manual_seed(n * 100 + w)
+    q = torch.randn(9, 16, n, h, w, device="cuda")
+    bias = torch.tensor([0.3], device="cuda")
+    out = torch.full((n, 1, 4 * h, 4 * w), float("nan"), device="cuda")
+    ops.head_q_gather(q, bias, out, n, h, w, 2.0, -1.0)
+    hr = q.double().reshape(9, 4, 4, n, h, w).permute(0, 3, 4, 1, 5, 2).reshape(9, n, 4 * h, 4 * w)       # [tap][n][4y+i][4x+j]
+    pad = torch.nn.functional.pad(hr, (1, 1, 1, 1))
+    want = torch.full((n, 4 * h, 4 * w), 0.3, dtype=torch.float64, device="cuda")
+    for ky in range(3):
+        for kx in range(3):
+            want += pad[ky * 3 + kx, :, ky:ky + 4 * h, kx:kx + 4 * w]
+    want = want * 2.0 - 1.0
+    assert float((out[:, 0].double() - want).abs().max()) <= 1e-5
