@@ -254,6 +254,83 @@ def gen_rdmodel(pssr):
     np.savez_compressed(OUT / "rdmodel.npz", **out)
 
 
+SCALE_CFGS = {
+    # upscaling factors that are not powers of two (pssr/models/_blocks.py:6-18 takes any int): name -> ResUNet kwargs + hw, n
+    "s3": dict(channels=1, hidden=[16, 32], scale=3, depth=1, hw=16, n=2),
+    "s6": dict(channels=[2, 1], hidden=[32, 64], scale=6, depth=0, hw=8, n=1),
+    "s5": dict(channels=[1, 3], hidden=[16, 32, 64], scale=5, depth=1, hw=16, n=1),
+}
+RD_SCALE_CFGS = {
+    "rd_s3": (dict(channels=1, hidden=[32, 32], scale=3, depth=1, rdnet_init=16, growth_rates=[8, 8, 16],
+                   ds_blocks=[False, False, True], ese_blocks=[True, False, True], n_blocks=[1, 2, 1]), 32, 2),
+}
+
+
+def gen_model_scales(pssr):
+    """ResUNet / RDResUNet with scale = 3, 5, 6 (own file: model.npz / rdmodel.npz stay as they were): the quantities gen_model /
+    gen_rdmodel record -- eval and train outputs, loss, running statistics, every parameter gradient."""
+    from pssr.models.rdresunet import RDResUNet
+    from pssr.models.resunet import ResUNet
+    out = {}
+
+    def record(name, model, x, cin):
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            y_eval = model(x)
+        model.train()
+        y_train = model(x)
+        target = torch.rand_like(y_train) * 255
+        loss = torch.nn.functional.mse_loss(y_train / 255, target / 255)
+        loss.backward()
+        out[f"{name}_x"], out[f"{name}_target"] = x.numpy(), target.numpy()
+        out[f"{name}_y_eval"], out[f"{name}_y_train"] = y_eval.numpy(), y_train.detach().numpy()
+        out[f"{name}_loss"] = np.array(loss.item())
+        for k, v in sd0.items():
+            out[f"{name}_sd/{k}"] = v.numpy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"{name}_sd_after/{k}"] = v.numpy()
+        for k, p in model.named_parameters():
+            out[f"{name}_grad/{k}"] = p.grad.numpy()
+        return y_eval
+
+    def shake(model):
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+                    m.running_mean.uniform_(-0.1, 0.1), m.running_var.uniform_(0.5, 1.5)
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.2, 0.2)
+            for pname, p in model.named_parameters():
+                if pname.endswith(".gamma"):
+                    p.uniform_(0.5, 1.5)
+                if ".fc.bias" in pname:
+                    p.uniform_(-2.0, 2.0)
+
+    for name, cfg in SCALE_CFGS.items():
+        cfg = dict(cfg)
+        torch.manual_seed(17)
+        hw, n = cfg.pop("hw"), cfg.pop("n")
+        model = ResUNet(**cfg)
+        cin = model.norm.num_features
+        shake(model)
+        x = torch.rand(n, cin, hw, hw) * 255
+        y_eval = record(name, model, x, cin)
+        out[f"{name}_cfg"] = np.array([n, cin, hw, cfg["scale"], cfg["depth"], len(cfg["hidden"]), y_eval.shape[1]])
+        out[f"{name}_hidden"] = np.array(cfg["hidden"])
+    for name, (kw, hw, n) in RD_SCALE_CFGS.items():
+        torch.manual_seed(19)
+        model = RDResUNet(**kw)
+        cin = model.norm.num_features
+        shake(model)
+        x = torch.rand(n, cin, hw, hw) * 255
+        record(name, model, x, cin)
+        out[f"{name}_skips"] = np.array(model.skips)
+    np.savez_compressed(OUT / "model_scales.npz", **out)
+
+
 def gen_init(pssr):
     """Pins that constructing the build's ResUNet under the same torch seed reproduces the
     reference's default initialisation (parameter creation order and shapes)."""
@@ -471,7 +548,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)   # deterministic summation order for the fixtures
     pssr = import_reference()
     only = sys.argv[1:]
-    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_init, gen_loss, gen_post, gen_metrics, gen_atrous, gen_train_trace):
+    for fn in (gen_bilinear, gen_pairs, gen_model, gen_rdmodel, gen_model_scales, gen_init, gen_loss, gen_post, gen_metrics, gen_atrous, gen_train_trace):
         if only and fn.__name__ not in only:
             continue
         fn(pssr)

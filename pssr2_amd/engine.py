@@ -10,7 +10,6 @@ memory, the stream and the autograd hook — no torch operator computes on the h
 """
 from __future__ import annotations
 
-import math
 
 import torch
 
@@ -20,11 +19,15 @@ from . import ops
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1     # torch.nn.BatchNorm2d defaults used by the reference blocks
 
 
-def _log2(v: int) -> int:
-    l = int(math.log2(v))
-    if (1 << l) != v:
-        raise ValueError(f"the MI355X path needs a power-of-two upscaling factor, got scale={v}")
-    return l
+def _blocked_order(r: int):
+    """How Reconstruction's F.pixel_shuffle(x, r) (pssr/models/_blocks.py:17) is carried out: (blk, explicit).  Power-of-two factors: the
+    high-resolution tensor IS `pre`'s output read in sub-pixel-blocked order (blk = log2 r: the kernels index it with shifts, nothing is
+    moved).  Any other factor (3, 5, 6 ...): blk = 0 and an explicit shuffle between `pre`'s low-resolution output and a plain
+    high-resolution tensor (pssr_pixel_shuffle; its inverse on the way back)."""
+    if r < 1:
+        raise ValueError(f"upscaling factor must be a positive integer, got scale={r}")
+    l = r.bit_length() - 1
+    return (l, False) if (1 << l) == r else (0, True)
 
 
 _COPY_BATCH = __import__("os").environ.get("PSSR_COPY_BATCH", "1") != "0"
@@ -368,13 +371,13 @@ class Engine:
         self.L = len(self.hidden)
         self.atrous = m.norm is None          # pssr/models/resunet.py:50: the atrous variant has no input BatchNorm
         self.r = m.reconstruction.scale
-        self.blk = _log2(self.r)
+        self.blk, self.explicit_shuffle = _blocked_order(self.r)
         self.xc = ops.pad_to(9 * self.cin, 16)
         h0 = self.h0 = self.hidden[0]
         r2 = self.r * self.r
-        # sub-pixel-major channel order of Reconstruction.pre: n' = sub*h0 + c  <-  n = c*r2 + sub
+        # sub-pixel-major channel order of Reconstruction.pre: n' = sub*h0 + c  <-  n = c*r2 + sub (explicit shuffle: torch's own order)
         idx = torch.arange(r2 * h0)
-        self.pre_perm = ((idx % h0) * r2 + idx // h0).to(torch.int32).to(device)
+        self.pre_perm = (idx if self.explicit_shuffle else (idx % h0) * r2 + idx // h0).to(torch.int32).to(device)
         self.pre_perm_long = self.pre_perm.long()
         self._convs = {}
         self._built_for = device
@@ -830,7 +833,9 @@ class Engine:
             return out
         ops.conv2d(feat, h0, cpre.get("fwd0", code), p.pre, r * r * h0, n=n, h=h, w=w, bias=p.pre_bias,
                    x1=p.xcol, cin1=self.xc, w1=cpre.get("fwd1", code), flags=L.FLAG_RELU)
-        pre_hr = p.pre.view(n, h * r, w * r, h0)
+        pre_hr = self._pre_hr(p)
+        if self.explicit_shuffle:
+            ops.pixel_shuffle(p.pre, pre_hr, n, h, w, h0, r, code)
         if ops.head_conv_supported(code, h0, self.cout):
             ops.head_conv_fwd(pre_hr, self.blk, rec.conv.weight, rec.conv.bias, out, n, h * r, w * r, h0, self.cout, 128.0, 128.0, code)
         else:
@@ -839,6 +844,20 @@ class Engine:
                        epilogue=L.EPI_FINAL, in0_blk=self.blk, out_scale=128.0, out_shift=128.0)
         return out
 
+    def _rows_head(self, code):
+        """head_conv_bwd_rows (one pass: data + weight gradient + pre's bias sums per (sub-pixel, channel)) takes this configuration."""
+        return ops.head_conv_supported(code, self.h0, self.cout) and not self.explicit_shuffle and self.blk <= 2 and self.h0 in (32, 64, 128)
+
+    def _pre_hr(self, p):
+        """Reconstruction.pre's activation as the high-resolution tensor the final convolution reads: a view in blocked order, or (factors
+        that are not powers of two) its own buffer filled by an explicit pixel shuffle."""
+        n, h, w, r, h0 = p.n, p.h, p.w, self.r, self.h0
+        if not self.explicit_shuffle:
+            return p.pre.view(n, h * r, w * r, h0)
+        if getattr(p, "pre_hr", None) is None:
+            p.pre_hr = torch.zeros(n, h * r, w * r, h0, dtype=p.pre.dtype, device=p.pre.device)
+        return p.pre_hr
+
     def _head_backward(self, p, bw, grads, dout, feat, dfeat):
         """Backward of the head: parameter gradients of Reconstruction, d(feat) into `dfeat`, d(xcol) into bw.dxcol_b."""
         rec = self.model.reconstruction
@@ -846,15 +865,20 @@ class Engine:
         dev = dout.device
         H, W = h * r, w * r
         dout = dout.contiguous().float()
-        pre_hr = p.pre.view(n, H, W, h0)
-        dpre_hr = bw.dpre.view(n, H, W, h0)
+        pre_hr = self._pre_hr(p)
+        if self.explicit_shuffle:
+            if getattr(bw, "dpre_hr", None) is None:
+                bw.dpre_hr = torch.zeros_like(pre_hr)
+            dpre_hr = bw.dpre_hr
+        else:
+            dpre_hr = bw.dpre.view(n, H, W, h0)
         if ops.head_conv_supported(code, h0, self.cout):
             # final conv straight from the f32 NCHW gradient ("x*128+128" folded into g_scale)
             gw = grads[id(rec.conv.weight)] = self._gbuf(rec.conv.weight)
             gb = torch.empty(2 * self.cout, dtype=torch.float32, device=dev)
             grads[id(rec.conv.bias)] = gb[:self.cout]
             # dgrad + wgrad + the bias sums of Reconstruction.pre in one pass over the HR activation
-            gpb = torch.empty(r * r * h0, dtype=torch.float32, device=dev) if (self.blk <= 2 and h0 in (32, 64, 128)) else None
+            gpb = torch.empty(r * r * h0, dtype=torch.float32, device=dev) if self._rows_head(code) else None
             if gpb is not None:
                 # order-independent sums (ops.head_conv_bwd_rows): dW and the bias sums land in zeroed f64 statistic buffers first.  The
                 # three statistic buffers of this stretch (output-gradient sums, dW, pre's bias sums) are slices of ONE allocation: one
@@ -889,6 +913,8 @@ class Engine:
                        aux=pre_hr, aux_scale=p.ones_pre, aux_shift=p.zeros_pre, out_blk=self.blk, aux_blk=self.blk)
         # ---- Reconstruction.pre (two sources)
         cpre_n = r * r * h0
+        if self.explicit_shuffle:
+            ops.pixel_shuffle(bw.dpre, dpre_hr, n, h, w, h0, r, code, inverse=True)
         if gpb is None:
             bw.sum64.zero_()
             ops.channel_sum_nhwc(bw.dpre, n * h * w, cpre_n, bw.sum64, code)
@@ -1047,7 +1073,7 @@ class Engine:
         h0 = hid[0]
         grads = {}
         plain = all(getattr(b, "a", None) is None for b in p.enc + p.dec) and p.epool is None and p.rpool is None
-        rows_head = ops.head_conv_supported(code, h0, self.cout) and self.blk <= 2 and h0 in (32, 64, 128)
+        rows_head = self._rows_head(code)
         self._overwrite_grads = plain and rows_head and not self.atrous and _OVERWRITE_GRADS
         self._begin_backward(dev)
         from . import atrous as A

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .engine import Engine, _Arena, _BNState, _Conv, _log2
+from .engine import Engine, _Arena, _BNState, _Conv, _blocked_order
 
 LN_EPS = 1e-6
 
@@ -80,14 +80,14 @@ class RDEngine(Engine):
         self.hidden = list(m.hidden)
         self.atrous = m.norm is None          # pssr/models/rdresunet.py:80
         self.r = m.reconstruction.scale
-        self.blk = _log2(self.r)
+        self.blk, self.explicit_shuffle = _blocked_order(self.r)
         self.ps = enc.patch_size
         self.xc = ops.pad_to(9 * self.cin, 16)
         self.pc = ops.pad_to(self.cin * self.ps * self.ps, 16)
         self.h0 = self.hidden[-1] // m.ratios[-1] ** 2
         h0, r2 = self.h0, self.r * self.r
         idx = torch.arange(r2 * h0)
-        self.pre_perm = ((idx % h0) * r2 + idx // h0).to(torch.int32).to(device)
+        self.pre_perm = (idx if self.explicit_shuffle else (idx % h0) * r2 + idx // h0).to(torch.int32).to(device)
         self.pre_perm_long = self.pre_perm.long()
         # stages: spatial level (number of down-samplings after the stem), skip index into the decoder (or None)
         ns = enc.num_stages

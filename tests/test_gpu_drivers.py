@@ -160,3 +160,43 @@ def test_reassemble_sheets_matches_reference_stitching(tmp_path):
         np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "out" / f"{sheet_name}.tif")), image[0])
     with pytest.raises(ValueError, match="margin"):
         reassemble_sheets(preds, str(tmp_path / "lr"), 4, overlap=2, margin=3, out_dir=None)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_scale_3_trains_and_predicts_through_the_drivers(dt, tmp_path):
+    """pssr/models/_blocks.py:6-18 takes any integer factor: scale = 3 (an explicit pixel shuffle in front of the final convolution instead of
+    the blocked order) through train_paired (device dataset: the hipGraph path) and predict_images, and the same steps launch by launch."""
+    import os
+    import random
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset, synthetic_em_tile
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.predict import predict_images
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+    tiles = np.stack([synthetic_em_tile(i, 96) for i in range(24)])
+
+    def run(graph):
+        os.environ["PSSR_GRAPH"] = "1" if graph else "0"
+        try:
+            torch.manual_seed(2)
+            random.seed(4)
+            np.random.seed(6)
+            ds = DeviceTileDataset(tiles, hr_res=96, lr_scale=3, crappifier=AdditiveGaussian(5), val_split=0.25, seed=3)
+            model = ResUNet(hidden=[16, 32], scale=3, depth=1).cuda()
+            model.compute_dtype = dt
+            tl, vl = train_paired(model, ds, 3, SSIMLoss(mix=0.8, ms=False), FusedAdamW(model.parameters(), lr=2e-3), epochs=3, device="cuda",
+                                  log_frequency=1)
+            return model, ds, tl, vl
+        finally:
+            os.environ.pop("PSSR_GRAPH", None)
+    model, ds, tl, vl = run(True)
+    assert all(np.isfinite(tl)) and all(np.isfinite(vl)) and np.mean(tl[-3:]) < np.mean(tl[:3])
+    _, _, tl0, vl0 = run(False)
+    np.testing.assert_allclose(tl, tl0, rtol=1e-4 if dt == torch.float32 else 2e-2)
+    preds = predict_images(model, ds, device="cuda", batch_size=4, out_dir=None)
+    assert len(preds) == len(ds.val_idx)
+    for v in preds.values():
+        v = v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        assert v.shape == (1, 96, 96) and v.dtype == np.uint8

@@ -51,9 +51,12 @@ def _load(g, name):
     return model.cuda(), torch.tensor(g[f"{name}_x"]).cuda()
 
 
-@pytest.mark.parametrize("name", ["tiny", "d1s2", "c33"])
-def test_reference_fixture_f32(golden, name):
-    g = golden("model.npz")
+# model_scales.npz: upscaling factors that are not powers of two (3, 6, 5 with three output channels) -- an explicit pixel shuffle between
+# Reconstruction.pre and the final convolution instead of the blocked order (Engine._pre_hr)
+@pytest.mark.parametrize("fixture,name", [("model.npz", "tiny"), ("model.npz", "d1s2"), ("model.npz", "c33"),
+                                          ("model_scales.npz", "s3"), ("model_scales.npz", "s6"), ("model_scales.npz", "s5")])
+def test_reference_fixture_f32(golden, fixture, name):
+    g = golden(fixture)
     model, x = _load(g, name)
     model.eval()
     with torch.no_grad():

@@ -11,6 +11,9 @@ RD_KW = {
                  ds_blocks=[False, True, True, True], ese_blocks=[False, False, True, True], n_blocks=[2, 2, 2, 2]),
     "rd_b": dict(channels=[3, 1], hidden=[32, 32], scale=2, depth=1, rdnet_init=16, growth_rates=[8, 8, 16],
                  ds_blocks=[False, False, True], ese_blocks=[True, False, True], n_blocks=[1, 2, 1]),
+    # model_scales.npz: a factor that is not a power of two (explicit pixel shuffle in front of the final convolution)
+    "rd_s3": dict(channels=1, hidden=[32, 32], scale=3, depth=1, rdnet_init=16, growth_rates=[8, 8, 16],
+                  ds_blocks=[False, False, True], ese_blocks=[True, False, True], n_blocks=[1, 2, 1]),
 }
 
 
@@ -48,11 +51,11 @@ def _cfg(kw):
     return R.RDConfig(**{**{k: tuple(v) if isinstance(v, list) else v for k, v in kw.items()}, "channels": ch})
 
 
-@pytest.mark.parametrize("name", ["rd_a", "rd_b"])
+@pytest.mark.parametrize("name", ["rd_a", "rd_b", "rd_s3"])
 def test_reference_fixture_f32(golden, name):
     from oracle import rdnet_ref as R
     from pssr2_amd.models import RDResUNet
-    g = golden("rdmodel.npz")
+    g = golden("model_scales.npz" if name == "rd_s3" else "rdmodel.npz")
     model = RDResUNet(**RD_KW[name])
     sd0 = {k.split("/", 1)[1]: torch.tensor(g[k]) for k in g.files if k.startswith(f"{name}_sd/")}
     model.load_state_dict(sd0)

@@ -11,9 +11,10 @@ def _sd(g, prefix):
     return {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "d1s2", "c33"])
-def test_resunet_forward_backward(golden, name):
-    g = golden("model.npz")
+@pytest.mark.parametrize("fixture,name", [("model.npz", "tiny"), ("model.npz", "d1s2"), ("model.npz", "c33"),
+                                          ("model_scales.npz", "s3"), ("model_scales.npz", "s6"), ("model_scales.npz", "s5")])
+def test_resunet_forward_backward(golden, fixture, name):
+    g = golden(fixture)
     n, cin, hw, scale, depth, nlev, cout = g[f"{name}_cfg"]
     sd = _sd(g, f"{name}_sd/")
     x = torch.tensor(g[f"{name}_x"])

@@ -11,6 +11,8 @@ RD_KW = {
                  ds_blocks=(False, True, True, True), ese_blocks=(False, False, True, True), n_blocks=(2, 2, 2, 2)),
     "rd_b": dict(channels=(3, 1), hidden=(32, 32), scale=2, depth=1, rdnet_init=16, growth_rates=(8, 8, 16),
                  ds_blocks=(False, False, True), ese_blocks=(True, False, True), n_blocks=(1, 2, 1)),
+    "rd_s3": dict(channels=(1, 1), hidden=(32, 32), scale=3, depth=1, rdnet_init=16, growth_rates=(8, 8, 16),
+                  ds_blocks=(False, False, True), ese_blocks=(True, False, True), n_blocks=(1, 2, 1)),
 }
 
 
@@ -18,9 +20,9 @@ def _sd(g, prefix):
     return {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
 
 
-@pytest.mark.parametrize("name", ["rd_a", "rd_b"])
+@pytest.mark.parametrize("name", ["rd_a", "rd_b", "rd_s3"])
 def test_rdresunet_forward_backward(golden, name):
-    g = golden("rdmodel.npz")
+    g = golden("model_scales.npz" if name == "rd_s3" else "rdmodel.npz")
     cfg = R.RDConfig(**RD_KW[name])
     assert cfg.skips == g[f"{name}_skips"].tolist()
     sd = _sd(g, f"{name}_sd/")
