@@ -1,4 +1,5 @@
 import sys; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
+import os
 import torch
 from pssr2_amd import ops, _lib as L
 dt = torch.bfloat16; code = L.BF16
@@ -21,6 +22,8 @@ for name, H, W, ci, co, taps in layers:
     ks = 3 if taps == 9 else 1
     x = torch.randn(N, H, W, ci, device="cuda").to(dt)
     w = torch.randn(co, ci, ks, ks, device="cuda") / (ci * taps) ** 0.5
+    if os.environ.get("MB_ZERO") == "1":        # all-zero operands: the same instruction stream without data toggling (is the clock power-limited?)
+        x.zero_(); w.zero_()
     pw = ops.pack_conv_weight(w, code)
     out = torch.zeros(N, H, W, max(co, 4), device="cuda", dtype=dt)
     sc, sh = torch.ones(ci, device="cuda"), torch.zeros(ci, device="cuda")
