@@ -49,7 +49,15 @@ def _slice_center(image, n_frames):
     return image[..., center - half:center + half + 1, :, :]
 
 
-def _tensor_ready(image, transforms):
+def _tensor_ready(image, transforms, compact=False):
+    """float32 tensor of an image (pssr/data.py:497-505).  ``compact``: uint8 instead -- what the drivers of this package ask their own
+    datasets for while they feed a captured graph from a DataLoader (every value here is an integer in [0, 255]: uint8 pixels, or the
+    rounded and clipped crappifier output); the conversion to float32 then happens on the device, and the worker -> pin-memory thread ->
+    PCIe path moves a quarter of the bytes."""
+    if compact and transforms is None:
+        u8 = np.ascontiguousarray(image).astype(np.uint8)
+        if image.dtype == np.uint8 or np.array_equal(u8, image):        # (a crappifier that returned NaN / a value outside [0, 255]: float32 as always)
+            return torch.from_numpy(u8)
     t = torch.tensor(np.ascontiguousarray(image).astype(np.float32), dtype=torch.float)
     if transforms is not None:
         for tr in transforms:
@@ -63,7 +71,7 @@ def _resize_bilinear_u8(hr, lr_res):
     return np.stack([np.asarray(Image.fromarray(ch).resize([lr_res] * 2, Image.Resampling.BILINEAR)) for ch in hr])
 
 
-def _gen_pair(hr, hr_res, lr_scale, rotation, crappifier, transforms, n_frames):
+def _gen_pair(hr, hr_res, lr_scale, rotation, crappifier, transforms, n_frames, compact=False):
     """Training pair from one uint8 HR stack [C, H, W] (pssr/data.py:471-495)."""
     hr = _pad_image(_square_crop(hr, hr_res), hr_res)
     if rotation:
@@ -78,11 +86,11 @@ def _gen_pair(hr, hr_res, lr_scale, rotation, crappifier, transforms, n_frames):
             hr = _slice_center(hr, n_frames[1])
         if not n_frames[0] > lr.shape[-3]:
             lr = _slice_center(lr, n_frames[0])
-    return _tensor_ready(hr, transforms), _tensor_ready(lr, transforms)
+    return _tensor_ready(hr, transforms, compact), _tensor_ready(lr, transforms, compact)
 
 
-def _ready_lr(lr, lr_res, transforms):
-    return _tensor_ready(_pad_image(_square_crop(lr, lr_res), lr_res), transforms)
+def _ready_lr(lr, lr_res, transforms, compact=False):
+    return _tensor_ready(_pad_image(_square_crop(lr, lr_res), lr_res), transforms, compact)
 
 
 def _n_tiles(image, size, stride):
@@ -176,6 +184,7 @@ class ArrayDataset(Dataset):
         self.hr_res, self.lr_scale = hr_res, lr_scale if lr_scale is not None else 1
         self.crappifier, self.rotation, self.transforms = crappifier, rotation, transforms
         self.extra_hr_files = None
+        self.compact = False        # True while train_paired feeds a captured graph from this dataset: uint8 items (see _tensor_ready)
         self.names = names if names is not None else [f"image{i}" for i in range(len(images))]
 
     def __len__(self):
@@ -188,8 +197,8 @@ class ArrayDataset(Dataset):
         rot = [bool(random.getrandbits(1)), random.choice((1, 2, (1, 2)))] if self.rotation and not is_val else False
         hr = self.images[idx]
         if self.is_lr:
-            return _ready_lr(hr, self.hr_res // self.lr_scale, self.transforms)
-        return _gen_pair(hr, self.hr_res, self.lr_scale, rot, self.crappifier, self.transforms, self.n_frames)
+            return _ready_lr(hr, self.hr_res // self.lr_scale, self.transforms, getattr(self, "compact", False))
+        return _gen_pair(hr, self.hr_res, self.lr_scale, rot, self.crappifier, self.transforms, self.n_frames, getattr(self, "compact", False))
 
     def _get_name(self, idx):
         return self.names[idx]
@@ -238,6 +247,7 @@ class SlidingArrayDataset(Dataset):
         self.crop_res, self.is_lr, self.extra_hr_files, self.n_frames = hr_res, True, None, None
         self.names = names if names is not None else [f"sheet{i}" for i in range(len(self.sheets))]
         self.transforms = transforms
+        self.compact = False        # see ArrayDataset.compact
 
     def __len__(self):
         return sum(self.tiles)
@@ -251,7 +261,7 @@ class SlidingArrayDataset(Dataset):
 
     def __getitem__(self, idx):
         s, t = self._locate(idx)
-        return _tensor_ready(_sliding_tile(self.sheets[s], self.hr_res, self.stride, t), self.transforms)
+        return _tensor_ready(_sliding_tile(self.sheets[s], self.hr_res, self.stride, t), self.transforms, getattr(self, "compact", False))
 
     def _get_name(self, idx):
         s, t = self._locate(idx)

@@ -94,6 +94,11 @@ def _all_ranks_ok(ok, device):
     return float(flag) >= 1.0
 
 
+def _feedable(t):
+    """A host batch as the feed takes it: float32, or uint8 as it is (a dataset of this package in compact mode: converted on the device)."""
+    return t if t.dtype in (torch.float32, torch.uint8) else t.float()
+
+
 class _HostFeed:
     """Static device inputs of a captured graph, refilled from host batches: the host-to-device copy of batch i + 1 runs on its own
     stream into one of two staging buffers while the graph of batch i is still running; a device-to-device copy (~15 us for a c2
@@ -106,11 +111,14 @@ class _HostFeed:
         self.static, self.stage, self.free_ev, self.keep, self.k = None, [None, None], [None, None], [None, None], 0
 
     def matches(self, tensors):
-        return self.static is not None and all(t.shape == s.shape for t, s in zip(tensors, self.static)) and len(tensors) == len(self.static)
+        return (self.static is not None and len(tensors) == len(self.static)
+                and all(t.shape == s.shape and t.dtype == g.dtype for t, s, g in zip(tensors, self.static, self.stage[0])))
 
     def allocate(self, tensors):
-        mk = lambda: [torch.empty(t.shape, dtype=torch.float32, device=self.device) for t in tensors]
-        self.static, self.stage = mk(), [mk(), mk()]
+        # the staging buffers take the batch as it arrives (float32, or the uint8 of a dataset in compact mode: a quarter of the bytes over
+        # PCIe); the copy into the graph's float32 buffers converts on the device
+        mk = lambda f32: [torch.empty(t.shape, dtype=torch.float32 if f32 else t.dtype, device=self.device) for t in tensors]
+        self.static, self.stage = mk(True), [mk(False), mk(False)]
 
     def push(self, tensors):
         k = self.k
@@ -255,12 +263,12 @@ class TrainStepper:
         """Next batch of the epoch (``batch``: the DataLoader's (hr, lr) host tensors in host mode).  Returns (hr, lr, hr_hat, loss)
         device tensors (static buffers once the graph is captured)."""
         if self.host:
-            hr, lr = (t if t.dtype == torch.float32 else t.float() for t in batch)
+            hr, lr = (_feedable(t) for t in batch)
             if self.feed.static is None and hr.shape[0] == self.batch:
                 self.feed.allocate((hr, lr))
             if hr.shape[0] != self.batch or not self.feed.matches((hr, lr)):      # partial last batch / another tile size: ordinary launches
                 self._leave_graph()
-                out = self._body((hr.to(self.device), lr.to(self.device)))
+                out = self._body((hr.to(self.device).float(), lr.to(self.device).float()))
                 self._after()
                 self._leave_graph()
                 return out
@@ -479,14 +487,14 @@ class EvalStepper:
     def step(self, batch=None):
         """``batch`` (host mode): the DataLoader's item -- (hr, lr) host tensors, or (lr,) for an LR-only dataset."""
         if self.host:
-            batch = tuple(t if t.dtype == torch.float32 else t.float() for t in batch)
+            batch = tuple(_feedable(t) for t in batch)
             if self.feed.static is None and batch[-1].shape[0] == self.batch:
                 self.feed.allocate(batch)
             self.count += 1
             if batch[-1].shape[0] != self.batch or not self.feed.matches(batch):
                 if self.weights_move:
                     self.engine.mark_weights_changed()
-                return self._run(tuple(t.to(self.device) for t in batch))
+                return self._run(tuple(t.to(self.device).float() for t in batch))
             self.feed.push(batch)
         else:
             left = self.n - self.pos

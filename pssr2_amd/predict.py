@@ -69,6 +69,7 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
     fast = fastpath.supports(model, dataset, device) and not dataloader_kwargs and len(idx) > 0
     host_fast = not fast and fastpath.supports_host(model, dataset, device) and len(idx) > 0
     keep_dev = bool(getattr(dataset, "device_outputs", False)) and not out_dir and not norm
+    compact = False
     if host_fast:
         # host batches (any dataset through a DataLoader): one captured forward over a static input buffer per (dataset, batch size)
         cache = model._engine.__dict__.setdefault("_eval_steppers", {})
@@ -79,6 +80,10 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
             evaler = cache[(id(dataset), batch_size, "host")] = fastpath.EvalStepper(model, dataset, batch_size, device, to_u8=True, weights_move=False,
                                                                                      host=True)
         evaler.begin()
+        # a dataset of this package hands the replay uint8 items (pssr2_amd/data.py: _tensor_ready); taken back when the loop below ends
+        compact = getattr(dataset, "compact", None) is False and os.environ.get("PSSR_HOST_COMPACT", "1") != "0"
+        if compact:
+            dataset.compact = True
         dataloader = DataLoader(dataset, batch_size, sampler=idx, **dataloader_kwargs)
     elif fast:
         # one stepper (and one captured graph) per (dataset, batch size): a second call over the same dataset only replays
@@ -92,7 +97,8 @@ def predict_images(model: nn.Module, dataset: Dataset, device: str = "cpu", batc
     else:
         dataloader = DataLoader(dataset, batch_size, sampler=idx, **dataloader_kwargs)
     outs, cur_idx = {}, first
-    with torch.no_grad():
+    from .train import _restore_compact
+    with torch.no_grad(), _restore_compact(dataset, host_fast and compact):
         for item in tqdm(dataloader, disable=rank != 0):
             if fast or host_fast:
                 hr_dev, lr, _, _, u8 = evaler.step() if fast else evaler.step((item,) if dataset.is_lr else tuple(item))

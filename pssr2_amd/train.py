@@ -45,6 +45,21 @@ def _collage(lr, hr_hat, hr, crop_res, lr_scale):
     return Image.fromarray(np.concatenate(rows, axis=0).astype(np.uint8))
 
 
+class _restore_compact:
+    """Takes the dataset out of compact (uint8 item) mode when the driver leaves, however it leaves."""
+
+    def __init__(self, dataset, active):
+        self.dataset, self.active = dataset, active
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.dataset.compact = False
+        return False
+
+
 def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: nn.Module, optim: torch.optim.Optimizer, epochs: int,
                  device: str = "cpu", scheduler=None, log_frequency: int = 50, checkpoint_dir: str = None, collage_dir: str = None,
                  clamp: bool = False, dataloader_kwargs=None, callbacks=None):
@@ -68,6 +83,11 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
     # host datasets (the reference's own ImageDataset / SlidingDataset through a DataLoader, workers and all): the same replay over
     # static input buffers, fed by one asynchronous host-to-device copy per batch
     host_fast = not fast and fastpath.supports_host(model, dataset, device)
+    # a dataset of this package feeding the replay hands over uint8 items (every value is an integer in [0, 255]); the feed converts on the
+    # device.  The flag travels to the DataLoader workers with the dataset and is taken back when the driver returns
+    compact = host_fast and getattr(dataset, "compact", None) is False and os.environ.get("PSSR_HOST_COMPACT", "1") != "0"
+    if compact:
+        dataset.compact = True
     if fast:
         train_dataloader = val_dataloader = None
     else:
@@ -94,7 +114,7 @@ def train_paired(model: nn.Module, dataset: Dataset, batch_size: int, loss_fn: n
 
     train_losses, val_losses = [], []
     # world > 1: an exception on one rank (a callback's, say) ends every rank within seconds (pssr2_amd/distributed.py: failure_watch)
-    with D.failure_watch("train_paired"):
+    with _restore_compact(dataset, compact), D.failure_watch("train_paired"):
         for epoch in range(epochs):
             model.train()
             if rank == 0:

@@ -220,6 +220,11 @@ def _run_train_host(host_graph, fused, pin):
                               dataloader_kwargs=dict(pin_memory=True) if pin else None)
         stp = getattr(model._engine, "last_train_stepper", None)
         assert (stp is not None and stp.host and stp.graph is not None) == host_graph
+        # the replay asks this package's datasets for uint8 items (a quarter of the bytes through the loader and over PCIe; converted on the
+        # device into the graph's float32 inputs) and hands the dataset back as it was
+        assert ds.compact is False and ds[0][0].dtype == torch.float32
+        if host_graph:
+            assert all(t.dtype == torch.uint8 for t in stp.feed.stage[0]) and all(t.dtype == torch.float32 for t in stp.feed.static)
         return tl, vl, {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, seen
     finally:
         os.environ.pop("PSSR_HOST_GRAPH", None)
