@@ -355,6 +355,17 @@ int pssr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int pssr_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t* state,
                         float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                         pssr_stream_t stream);
+/* Dynamic loss scaling without the host (fp16 storage, BASELINE config 4; the reference trains in fp32: no upstream counterpart;
+ * policy = torch.amp.GradScaler's).  `amp` is a device int32[4]: [0] loss scale (f32 bits) -- the caller multiplies the loss by it --,
+ * [1] good steps in a row, [2] steps skipped, [3] a gradient of the current step is not finite.
+ *   pssr_amp_check       sets amp[3] when any of the n gradients is inf / NaN.
+ *   pssr_adamw_step_amp  pssr_adamw_step_dev with the gradients divided by the scale; when amp[3] is set neither the step count nor a
+ *                        parameter moves; afterwards the scale is multiplied by `backoff` (skipped step) or, every `interval` good
+ *                        steps, by `growth`, and amp[3] is cleared.  Everything in stream order: a whole fp16 step replays as a graph. */
+int pssr_amp_check(const float* g, int64_t n, int32_t* amp, pssr_stream_t stream);
+int pssr_adamw_step_amp(float* p, const float* g, float* m, float* v, int64_t n, int64_t* state,
+                        float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                        int32_t* amp, float growth, float backoff, int interval, pssr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pair generation / crappifiers (pssr/data.py:471-495, pssr/crappifiers.py).

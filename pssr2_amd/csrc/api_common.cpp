@@ -18,7 +18,7 @@ void pssr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pssr_last_error(void) { return g_err; }
-extern "C" int pssr_abi_version(void) { return 3; }
+extern "C" int pssr_abi_version(void) { return 4; }
 
 // ---- kernel-selection tunables: ONE process-wide table, filled once from the environment (PSSR_<NAME>) the first time any entry
 // point asks, changed afterwards only through pssr_set_option().  No launch path reads the environment.

@@ -184,10 +184,12 @@ class TrainStepper:
         self.engine = model._engine
         self.rank, self.world = D.rank_world()
         self.fused = isinstance(optim, FusedAdamW)
-        self.in_graph_optim = self.fused and self.world == 1 and scaler is None
+        # fp16 storage: the loss scaler's policy runs on the device (LossScaler.step_dev), so the optimizer stays inside the graph
+        self.amp_dev = scaler is not None and self.fused and self.world == 1 and os.environ.get("PSSR_AMP_DEVICE", "1") != "0"
+        self.in_graph_optim = self.fused and self.world == 1 and (scaler is None or self.amp_dev)
         if self.fused:
             optim.device_state = True
-        self.scale_dev = torch.ones(1, device=device) if scaler is not None else None
+        self.scale_dev = (scaler.to_device(device).scale_dev if self.amp_dev else torch.ones(1, device=device)) if scaler is not None else None
         self.host = host               # batches arrive from a DataLoader (host tensors) instead of being made on the device
         self.cur = _Cursor(dataset, batch_size, capacity, device) if not host else None
         self.feed = _HostFeed(device) if host else None
@@ -233,7 +235,10 @@ class TrainStepper:
     def _body(self, rows=None):
         out = self._fwd_bwd(rows)
         if self.in_graph_optim:
-            self.optim.step()
+            if self.amp_dev:
+                self.scaler.step_dev(self.optim, self.engine._flat_grad)
+            else:
+                self.optim.step()
             self.optim.zero_grad()      # Python only (.grad = None): the next backward publishes views of the flat buffer again
         return out
 
@@ -284,7 +289,7 @@ class TrainStepper:
                 return out
             self.pos += self.batch
         if self.graph is None and self.eager_done < self.WARM:
-            if self.scaler is not None:
+            if self.scaler is not None and not self.amp_dev:
                 self.scale_dev.fill_(self.scaler.scale_value)
             out = self._body()                              # real steps that double as warm-up (weights end up stale: the capture
             self._after()                                   # below then contains the packed-weight refresh)
@@ -422,6 +427,8 @@ class TrainStepper:
 
     def finish(self):
         self._leave_graph()
+        if self.amp_dev:
+            self.scaler.pull()          # scale / good / skipped counters back on the host attributes (one synchronisation per epoch)
 
 
 class EvalStepper:

@@ -392,6 +392,17 @@ def adamw_step_dev(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scal
                                         L.stream_ptr()), "pssr_adamw_step_dev")
 
 
+def amp_check(g, amp):
+    """amp[3] |= any(g is inf / NaN); amp: device int32[4] (see include/pssr_mi355.h)."""
+    L.check(L.lib().pssr_amp_check(L.ptr(g), C.c_int64(g.numel()), L.ptr(amp), L.stream_ptr()), "pssr_amp_check")
+
+
+def adamw_step_amp(p, g, m, v, state, beta1, beta2, eps, weight_decay, amp, growth, backoff, interval, grad_scale=1.0):
+    L.check(L.lib().pssr_adamw_step_amp(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), L.ptr(state), C.c_float(beta1),
+                                        C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_float(grad_scale), L.ptr(amp),
+                                        C.c_float(growth), C.c_float(backoff), int(interval), L.stream_ptr()), "pssr_adamw_step_amp")
+
+
 # ----------------------------------------------------------------------------------------------
 # RDNet encoder kernels (csrc/rdnet.hip)
 def input_patchify(x, xpatch, scale, shift, patch, dtype, pre_scale=1 / 128, pre_shift=-1.0):

@@ -36,7 +36,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, amp=None):
+        """``amp`` (device_state mode): ``(state, growth, backoff, interval)`` of a ``LossScaler`` kept on the device -- the step is skipped
+        and the scale adapted there (pssr_adamw_step_amp), nothing comes back to the host."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -74,7 +76,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     import struct
                     st["dev"][1] = struct.unpack("<I", struct.pack("<f", float(group["lr"])))[0]
                     st["dev_lr"] = group["lr"]
-                ops.adamw_step_dev(st["flat"], g, st["m"], st["v"], st["dev"], b1, b2, group["eps"], group["weight_decay"], grad_scale)
+                if amp is not None:
+                    ops.adamw_step_amp(st["flat"], g, st["m"], st["v"], st["dev"], b1, b2, group["eps"], group["weight_decay"], amp[0], amp[1], amp[2],
+                                       amp[3], grad_scale)
+                else:
+                    ops.adamw_step_dev(st["flat"], g, st["m"], st["v"], st["dev"], b1, b2, group["eps"], group["weight_decay"], grad_scale)
             else:
                 ops.adamw_step(st["flat"], g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
                                grad_scale)
@@ -108,11 +114,52 @@ class LossScaler:
     def __init__(self, init_scale=2.0 ** 12, growth_factor=2.0, backoff_factor=0.5, growth_interval=200):
         self.scale_value, self.growth, self.backoff, self.interval = float(init_scale), growth_factor, backoff_factor, growth_interval
         self.good_steps, self.skipped = 0, 0
+        self.amp = None         # device mode (to_device): int32[4] = scale (f32 bits), good steps, skipped steps, non-finite flag
 
     def scale(self, loss):
         return loss * self.scale_value
 
+    # ---- device mode: the whole policy runs in stream order (pssr_amp_check / pssr_adamw_step_amp), so that an fp16 step -- loss scaling,
+    # finiteness check, skipped-or-taken FusedAdamW step, scale update -- replays as one hipGraph without a host round trip per step
+    def to_device(self, device):
+        if self.amp is None or self.amp.device != torch.device(device):
+            self.amp = torch.zeros(4, dtype=torch.int32, device=device)
+            self.push()
+        return self
+
+    @property
+    def scale_dev(self):
+        """The loss scale as a device float32[1] (a view of the state: what the captured step multiplies the loss by)."""
+        return self.amp.view(torch.float32)[0:1]
+
+    def push(self):
+        """Host attributes -> device state."""
+        self.amp.copy_(torch.tensor([0, self.good_steps, self.skipped, 0], dtype=torch.int32))
+        self.amp.view(torch.float32)[0:1].fill_(self.scale_value)
+
+    def pull(self):
+        """Device state -> host attributes (synchronises; the drivers call it when an epoch ends)."""
+        if self.amp is not None:
+            host = self.amp.cpu()
+            self.scale_value = float(host.view(torch.float32)[0])
+            self.good_steps, self.skipped = int(host[1]), int(host[2])
+        return self
+
+    def step_dev(self, optim, flat_grad, grad_scale=1.0):
+        """One optimizer step under the device-side policy; ``flat_grad``: the f32 buffer holding every gradient the step reads."""
+        ops.amp_check(flat_grad, self.amp)
+        optim.step(grad_scale=grad_scale, amp=(self.amp, self.growth, self.backoff, self.interval))
+
     def step(self, optim, params):
+        if self.amp is not None:            # host-side step of a scaler that also lives on the device: keep the two in step
+            self.pull()
+            try:
+                return self._step_host(optim, params)
+            finally:
+                self.push()
+        return self._step_host(optim, params)
+
+    def _step_host(self, optim, params):
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
             return False

@@ -344,3 +344,76 @@ def test_uncapturable_loss_falls_back_to_eager_launches(capsys):
     tl0, vl0, _ = run(False)
     np.testing.assert_allclose(tl, tl0, rtol=2e-5)
     np.testing.assert_allclose(vl, vl0, rtol=2e-5)
+
+
+def test_loss_scaler_policy_on_the_device():
+    """pssr_amp_check / pssr_adamw_step_amp (LossScaler.step_dev): finite gradients -> the FusedAdamW step of the host policy with the
+    gradients divided by the scale; a non-finite gradient -> no parameter, moment or step count moves, the scale halves; `interval` good
+    steps in a row double it.  Against the host-side LossScaler on identical buffers."""
+    from pssr2_amd.optim import FusedAdamW, LossScaler
+
+    def make():
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(1000, device="cuda")), torch.nn.Parameter(torch.randn(37, 5, device="cuda"))]
+        opt = FusedAdamW(ps, lr=1e-2)
+        return ps, opt
+    g = torch.Generator(device="cuda").manual_seed(1)
+    grads = [[torch.randn(1000, device="cuda", generator=g) * 64, torch.randn(37, 5, device="cuda", generator=g) * 64] for _ in range(5)]
+    grads[2][1][3, 2] = float("inf")                   # step 3 overflows
+    grads[3][0][7] = float("nan")                      # step 4 too
+    res = {}
+    for dev_mode in (False, True):
+        ps, opt = make()
+        sc = LossScaler(init_scale=64.0, growth_interval=2)
+        if dev_mode:
+            opt.device_state = True
+            sc.to_device("cuda")
+        for gs in grads:
+            for p, gg in zip(ps, gs):
+                p.grad = gg.clone()
+            if dev_mode:
+                flat = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in ps])
+                sc.step_dev(opt, flat)
+            else:
+                sc.step(opt, ps)
+        if dev_mode:
+            steps_dev = int(opt._flat[0]["dev"][0])
+            sc.pull()
+            assert steps_dev == 3                      # two skipped steps did not advance AdamW's bias correction
+        res[dev_mode] = ([p.detach().clone() for p in ps], sc.scale_value, sc.good_steps, sc.skipped)
+    (pa, sa, ga, ka), (pb, sb, gb, kb) = res[False], res[True]
+    assert (sa, ga, ka) == (sb, gb, kb) == (64.0 * 2 * 0.5 * 0.5, 1, 2)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+
+
+def test_fp16_training_replays_with_the_scaler_on_the_device():
+    """fp16 storage through train_paired: the whole step -- loss scaling, finiteness check, FusedAdamW, scale update -- is one replayed
+    graph (no host round trip per step) and gives what the launch-by-launch loop with the host-side scaler gives."""
+    from pssr2_amd.crappifiers import AdditiveGaussian
+    from pssr2_amd.data import DeviceTileDataset
+    from pssr2_amd.models import ResUNet
+    from pssr2_amd.optim import FusedAdamW
+    from pssr2_amd.train import train_paired
+    from pssr2_amd.util import SSIMLoss
+
+    def run(graph):
+        os.environ["PSSR_GRAPH"] = "1" if graph else "0"
+        try:
+            torch.manual_seed(3)
+            random.seed(11)
+            np.random.seed(5)
+            model = ResUNet(hidden=[16, 32], depth=1).cuda()
+            model.compute_dtype = torch.float16
+            ds = DeviceTileDataset(_tiles(44, 64), hr_res=64, lr_scale=4, crappifier=AdditiveGaussian(9, 0, 0), val_split=0.2, seed=2)
+            tl, vl = train_paired(model, ds, 8, SSIMLoss(ms=False, win_size=7), FusedAdamW(model.parameters(), lr=2e-3, eps=1e-3), 3, device="cuda",
+                                  log_frequency=1)
+            return tl, vl, getattr(model._engine, "last_train_stepper", None)
+        finally:
+            os.environ.pop("PSSR_GRAPH", None)
+    tl, vl, stp = run(True)
+    assert stp is not None and stp.graph is not None and stp.amp_dev and stp.in_graph_optim
+    assert stp.scaler.skipped == 0 and stp.scaler.good_steps == len(tl) and stp.scaler.scale_value == 2.0 ** 12
+    tl0, vl0, _ = run(False)
+    np.testing.assert_allclose(tl, tl0, rtol=2e-3)
+    np.testing.assert_allclose(vl, vl0, rtol=2e-3)
