@@ -118,9 +118,14 @@ enum {
     PSSR_FLAG_HEADQ = 8,  /* EPI_STORE (with FLAG_RELU): store the activation AND the tap planes of PSSR_EPI_HEADQ (same conditions, head_w /
                              head_q set): the training form -- `pre`'s activation is kept for the backward pass, Reconstruction.conv's
                              forward still needs no pass over it */
-    PSSR_FLAG_AFFINE = 4  /* EPI_STORE, 16-bit storage, not with FLAG_STATS: out = (acc + bias) * aux_scale + aux_shift (then FLAG_RELU):
+    PSSR_FLAG_AFFINE = 4, /* EPI_STORE, 16-bit storage, not with FLAG_STATS: out = (acc + bias) * aux_scale + aux_shift (then FLAG_RELU):
                              an eval-mode BatchNorm (+ ReLU) applied by the PRODUCING convolution on its f32 accumulators
                              (_blocks.py:28-32 in eval mode), so that the next layer's loader needs no prologue */
+    PSSR_FLAG_SHUF2 = 16  /* EPI_STORE, 16-bit storage, cout % 32 == 0, not with FLAG_STATS / FLAG_HEADQ: F.pixel_shuffle(out, 2)
+                             (resunet.py:82) done by the store.  `out` is the [n, 2h, 2w, out_cstride] buffer the shuffled map belongs
+                             into (channels out_coff .. out_coff + cout / 4); the weights (and bias) arrive with their output channels
+                             in sub-pixel-major order (packed row s * cout / 4 + c = torch channel 4 c + s, s = 2 i + j), and the
+                             8-channel piece c of sub-pixel (i, j) of pixel (y, x) goes to pixel (2 y + i, 2 x + j), channel c */
 };
 
 typedef struct pssr_conv_desc {

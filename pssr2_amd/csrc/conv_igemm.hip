@@ -45,7 +45,8 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
         PSSR_CHECK(d->cout > 0 && d->cout <= 32 && d->flags == 0, PSSR_ERR_ARG, "conv2d: EPI_FINAL needs 0 < cout <= 32 and no flags");
     } else {
         PSSR_CHECK(d->cout > 0 && d->cout % 4 == 0, PSSR_ERR_ARG, "conv2d: cout=%d must be a positive multiple of 4", d->cout);
-        PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 && d->out_coff + d->cout <= d->out_cstride, PSSR_ERR_ARG, "conv2d: out stride/offset");
+        PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 &&
+                   d->out_coff + ((d->flags & PSSR_FLAG_SHUF2) ? d->cout / 4 : d->cout) <= d->out_cstride, PSSR_ERR_ARG, "conv2d: out stride/offset");
     }
     PSSR_CHECK(d->n_pad % 128 == 0 && d->n_pad >= d->cout, PSSR_ERR_ARG, "conv2d: n_pad=%d", d->n_pad);
     PSSR_CHECK(d->prologue >= 0 && d->prologue <= PSSR_PRO_GELU, PSSR_ERR_ARG, "conv2d: prologue=%d", d->prologue);
@@ -69,6 +70,12 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
     }
     if (d->epilogue == PSSR_EPI_DGRAD_GELU)
         PSSR_CHECK(d->aux && d->aux_coff % 4 == 0 && d->aux_cstride % 4 == 0, PSSR_ERR_ARG, "conv2d: GELU backward needs the pre-activation as aux");
+    if (d->flags & PSSR_FLAG_SHUF2) {
+        PSSR_CHECK(d->epilogue == PSSR_EPI_STORE && !(d->flags & (PSSR_FLAG_STATS | PSSR_FLAG_HEADQ)) && d->out_blk == 0, PSSR_ERR_ARG,
+                   "conv2d: FLAG_SHUF2 goes with EPI_STORE, without statistics, tap planes or a blocked output order");
+        PSSR_CHECK(esz == 2 && d->cout % 32 == 0 && d->out_coff % 8 == 0 && d->out_cstride % 8 == 0 && pssr_tunables().conv_epi8, PSSR_ERR_UNSUPPORTED,
+                   "conv2d: FLAG_SHUF2 needs 16-bit storage, cout a multiple of 32 and 8-channel aligned outputs");
+    }
     if (d->flags & PSSR_FLAG_AFFINE) {
         PSSR_CHECK(d->epilogue == PSSR_EPI_STORE && !(d->flags & PSSR_FLAG_STATS) && d->aux_scale && d->aux_shift, PSSR_ERR_ARG,
                    "conv2d: FLAG_AFFINE needs EPI_STORE without statistics and aux_scale / aux_shift");

@@ -288,6 +288,14 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     T* outp = (T*)p.out + p.out_co + n_base;
     const T* auxp = (const T*)p.aux + p.aux_co + n_base;
+    // FLAG_SHUF2: the piece belongs to sub-pixel shuf_s = (i, j) of its pixel and to channel n_base % (cout / 4) of the shuffled map
+    const bool shuf = EPI == PSSR_EPI_STORE && !STATS && (p.flags & PSSR_FLAG_SHUF2);
+    int shuf_i = 0, shuf_j = 0;
+    if (shuf) {
+        const int q4 = p.cout >> 2, s = n_base / q4;
+        shuf_i = s >> 1; shuf_j = s & 1;
+        outp = (T*)p.out + p.out_co + (n_base - s * q4);
+    }
 
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi) {
@@ -338,7 +346,8 @@ __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, f32x16 (&acc)[
                     s2[e] += g[e] * (EPI == PSSR_EPI_STORE ? g[e] : a[e]);
                 }
             }
-            *(u32x4*)(outp + pix_index(gi, gy, gx, p.H, p.W, p.out_blk) * p.out_cs) = packed;
+            const long opix = shuf ? ((long)gi * 2 * p.H + 2 * gy + shuf_i) * (2 * p.W) + 2 * gx + shuf_j : pix_index(gi, gy, gx, p.H, p.W, p.out_blk);
+            *(u32x4*)(outp + opix * p.out_cs) = packed;
         }
     }
     if (STATS) {

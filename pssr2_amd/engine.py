@@ -44,6 +44,7 @@ _NO_MATERIALISE = __import__("os").environ.get("PSSR_MATERIALISE", "0") != "1"
 # apply (bn_bwd_apply), relustats (relu_bwd_stats), unpack (partial-slab reduction of the weight gradients), gzero (flat gradient memset)
 _FUSE_DOUT = __import__("os").environ.get("PSSR_FUSE_DOUT", "1") != "0"
 _OVERWRITE_GRADS = __import__("os").environ.get("PSSR_OVERWRITE_GRADS", "1") != "0"
+_EVAL_SHUF = __import__("os").environ.get("PSSR_EVAL_SHUF", "1") != "0"         # eval mode: F.pixel_shuffle(x, 2) done by the producing conv's stores (FLAG_SHUF2)
 _EVAL_AFFINE = __import__("os").environ.get("PSSR_EVAL_AFFINE", "1") != "0"     # eval mode: BatchNorm + ReLU in the producing conv's epilogue (FLAG_AFFINE)
 _HEAD_FUSE = __import__("os").environ.get("PSSR_HEAD_FUSE", "1") != "0"      # eval mode: Reconstruction.conv inside pre's epilogue (EPI_HEADQ)
 _ABL = frozenset(x for x in __import__("os").environ.get("PSSR_ABLATE", "").split(",") if x)
@@ -652,24 +653,40 @@ class Engine:
             fn()
         self._fwd_side = True
 
-    def _folded_last(self, module, st, conv, code):
+    def _folded_last(self, module, st, conv, code, perm=None):
         """(packed weight, bias) of a block's last convolution with its eval-mode BatchNorm folded in: W' = W * scale[co],
-        b' = conv.bias * scale + shift + respass.bias.  Cached per (parameter versions, BatchNorm affine)."""
+        b' = conv.bias * scale + shift + respass.bias.  Cached per (parameter versions, BatchNorm affine).  ``perm`` (int64 [cout]): output
+        channels in that order (FLAG_SHUF2: sub-pixel-major)."""
         cache = self.__dict__.setdefault("_fold_cache", {})
         rp = module.respass
         key = (self._wepoch[0], conv.weight._version, conv.bias._version, rp.bias._version, st.eval_key)
-        ent = cache.get((id(conv), code))
+        ck = (id(conv), code, perm is not None)
+        ent = cache.get(ck)
         if ent is None or ent[0] != key:
             with torch.no_grad():
-                wf = (conv.weight.detach() * st.scale.view(-1, 1, 1, 1)).contiguous()
+                wf = conv.weight.detach() * st.scale.view(-1, 1, 1, 1)
                 bf = torch.addcmul(st.shift, conv.bias.detach(), st.scale).add_(rp.bias.detach())
+                if perm is not None:
+                    wf, bf = wf[perm], bf[perm]
+                wf = wf.contiguous()
             pw = ops.pack_conv_weight(wf, code, mode=0, out=ent[1] if ent is not None else None)
             if ent is not None:                 # in place: a captured eval graph (fastpath.EvalStepper) holds these two buffers by address
                 bf = ent[2].copy_(bf)
-            ent = cache[(id(conv), code)] = (key, pw, bf)
+            ent = cache[ck] = (key, pw, bf)
         return ent[1], ent[2]
 
-    def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train):
+    def _shuf_perm(self, c, device):
+        """Sub-pixel-major order of a block output that goes through F.pixel_shuffle(x, 2): row s * c / 4 + q <- torch channel 4 q + s."""
+        cache = self.__dict__.setdefault("_shuf_perms", {})
+        if (c, device) not in cache:
+            idx = torch.arange(c, device=device)
+            perm = (idx % (c // 4)) * 4 + idx // (c // 4)
+            cache[(c, device)] = (perm, perm.to(torch.int32))
+        return cache[(c, device)]
+
+    def _block_forward(self, p, blk, module, src, cin, first, dst, dst_coff, train, shuf=None):
+        """``shuf``: the [n, 2h, 2w, .] concat buffer whose first c / 4 channels are F.pixel_shuffle(block output, 2).  Returns True when the
+        block wrote them there itself (eval mode: FLAG_SHUF2 on its last convolution; ``dst`` is then left unwritten), else None."""
         if getattr(blk, "a", None) is not None:          # ResBlockA (pssr2_amd/atrous.py); a first block reads the plain input
             from . import atrous as A
             A.ablock_forward(self, blk.a, module, p.xin if first else src, 0, p.n, p.code, dst, dst_coff, train)
@@ -706,6 +723,14 @@ class Engine:
                 else:
                     pwr = self._conv(rp, fwd=dict(mode=0), dgrad=dict(mode=1)).get("fwd", p.code)
                 if spec["fwd"]["mode"] == 0:
+                    if shuf is not None and _EVAL_SHUF and blk.c % 32 == 0 and not first:
+                        # the consumer of this block is F.pixel_shuffle(., 2) into a concat buffer: the stores go there directly
+                        perm_l, perm_i = self._shuf_perm(blk.c, inp.device)
+                        pwf, bf = self._folded_last(module, blk.bn[k], conv, p.code, perm_l)
+                        pwr = self._pw_any(rp, "fwd_shuf", p.code, mode=0, n_perm=perm_i)
+                        ops.conv2d(inp, icn, pwf, shuf, blk.c, n=n, h=hh, w=ww, out_coff=0, bias=bf, x1=src, cin1=cin, w1=pwr,
+                                   flags=L.FLAG_RELU | L.FLAG_SHUF2)
+                        return True
                     pwf, bf = self._folded_last(module, blk.bn[k], conv, p.code)
                     ops.conv2d(inp, icn, pwf, dst, blk.c, n=n, h=hh, w=ww, out_coff=dst_coff, bias=bf, x1=src, cin1=cin, w1=pwr,
                                flags=L.FLAG_RELU)
@@ -777,7 +802,9 @@ class Engine:
                 dst, off = p.cat[i], hid[i + 1] // 4
             else:
                 dst, off = blk.out, 0
-            self._block_forward(p, blk, m.encoder[i], src, cin, i == 0, dst, off, train)
+            # (the deepest block feeds the first pixel shuffle of the decoder -- unless PSP pooling sits in between)
+            shuffled = self._block_forward(p, blk, m.encoder[i], src, cin, i == 0, dst, off, train,
+                                           shuf=p.cat[Lv - 2] if (i == Lv - 1 and Lv > 1 and p.epool is None and not train) else None)
             if i < Lv - 1 and "pool" not in _ABL:
                 ops.maxpool2(dst, p.pooled[i], n, *p.dims[i], hid[i], code, in_coff=off)
         deep = p.enc[Lv - 1].out
@@ -788,10 +815,11 @@ class Engine:
         # decoder
         for l in range(Lv - 2, -1, -1):
             prev = deep if l == Lv - 2 else p.dec[l + 1].out
-            if "shuf" not in _ABL:
+            if "shuf" not in _ABL and not shuffled:       # (shuffled: the block before stored into cat[l] itself)
                 ops.pixel_shuffle(prev, p.cat[l], n, *p.dims[l + 1], hid[l + 1] // 4, 2, code)
             blk = p.dec[l]
-            self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train)
+            shuffled = self._block_forward(p, blk, m.decoder[Lv - 2 - l], p.cat[l], p.cat[l].shape[-1], False, blk.out, 0, train,
+                                           shuf=p.cat[l - 1] if (l > 0 and not train) else None)
         feat = p.dec[0].out if Lv > 1 else deep
         if p.rpool is not None:         # pssr/models/resunet.py:87-88
             from . import atrous as A
