@@ -420,6 +420,11 @@ class Engine:
             import ctypes as C
             arr = (L.PackItem * len(stale))(*[c.item(*key) for c, key in stale])
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            if code in cache:
+                # a captured graph (a training or validation step of fastpath.py) may hold the previous table BY ADDRESS: a pass that packs
+                # new forms after that capture (the eval-mode forms of a validation pass, say) changes the set, and a freed table read by
+                # the old graph's re-pack launch is a kernel writing through stale pointers.  Tables are a few KB: never handed back
+                self.__dict__.setdefault("_pack_tables_kept", []).append(cache[code][1])
             cache[code] = (sig, host.to(stale[0][0].m.weight.device))
         L.check(L.lib().pssr_pack_conv_weight_batch(L.ptr(cache[code][1]), len(stale), L.stream_ptr()), "pssr_pack_conv_weight_batch")
         for c, key in stale:
