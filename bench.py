@@ -721,12 +721,13 @@ def main():
             model_rd = RDResUNet().to(dev)
             model_rd.compute_dtype = torch.bfloat16
             ds_rd = DeviceTileDataset(tiles_dev[:1024], hr_res=hr_res, lr_scale=4, crappifier=Poisson(), val_split=0.1, rotation=True, device=dev, seed=8)
-            t_rd, _ = run_train(model_rd, ds_rd, 32, 3, 8)
-            v_rd = 32 * 8 / t_rd
+            rd_steps = 16
+            t_rd, _ = run_train(model_rd, ds_rd, 32, 4, rd_steps)
+            v_rd = 32 * rd_steps / t_rd
             res["rd_train"] = {"metric": f"HR tiles/sec ({hr_res}^2 4xSR) train", "value": round(v_rd, 2), "unit": "HR tiles/s", "dtype": "bf16",
-                               "ms_per_step": round(1e3 * t_rd / 8, 3),
+                               "ms_per_step": round(1e3 * t_rd / rd_steps, 3),
                                "config": "BASELINE config 3 on one GPU: RDResUNet 1-ch 128^2->512^2, Poisson() device crappifier, MS-SSIM+L1, FusedAdamW, "
-                                         "batch 32, train_paired (hipGraph replay), 8 timed steps",
+                                         f"batch 32, train_paired (hipGraph replay), {rd_steps} timed steps",
                                "roofline": whole_pass_roofline(round(v_rd * 321.45 / 1e3, 2), "whole training step (pair generation, forward, loss, backward, "
                                                                "optimizer); algorithmic FLOPs of the convolutions (SURVEY.md 8d: 321.45 GFLOP per tile)",
                                                                traffic=pass_traffic("rdresunet_train")),
