@@ -31,6 +31,7 @@ const Entry kEntries[] = {
     {"IGEMM_V3_64", &PssrTunables::igemm_v3_64, 1, 0, 1},
     {"V3_LDS_PAD", &PssrTunables::v3_lds_pad, 0, 0, 100},
     {"IGEMM_DBG", &PssrTunables::igemm_dbg, 0, 0, 255},
+    {"IGEMM_N64", &PssrTunables::igemm_n64, 1, 0, 1},
     {"IGEMM_KSPLIT", &PssrTunables::igemm_ksplit, 384, 1, 1 << 20},
     {"CONV_EPI8", &PssrTunables::conv_epi8, 1, 0, 1},
     {"WGRAD_LEAN", &PssrTunables::wgrad_lean, 1, 0, 1},

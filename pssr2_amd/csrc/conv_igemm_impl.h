@@ -1120,6 +1120,15 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
         PSSR_CHECK(a.epi != PSSR_EPI_HEADQ && !(a.flags & PSSR_FLAG_HEADQ), PSSR_ERR_UNSUPPORTED, "conv2d: EPI_HEADQ needs 16-bit storage");
         if constexpr (sizeof(T) == 2) { if (use_v3<T, 128>(a)) return launch3_t<T, 128>(a, s); }
         if constexpr (sizeof(T) == 2) {
+            // layers whose 128 x 128 tiles give about ONE workgroup per CU (512 channels on the 16 x 16 maps at batch 32) take 128 x 64 tiles:
+            // two co-resident workgroups cover each other's barriers and staging latency (512 -> 512 @16^2 57.0 -> 45.2 us, 768 -> 512
+            // 72.3 -> 62.8; inside the training step the gain is absorbed, forward-only passes at that batch size run 1.8 % faster)
+            if (pssr_tunables().igemm_n64 && a.taps[0] == 9 && a.W > 8) {
+                const long b128 = (long)cdiv(a.W, 16) * cdiv(a.H, 8) * a.N * cdiv(a.cout, 128);
+                if (b128 >= 192 && b128 <= 320) return launch<T, 64, 0>(a, s);
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
             if (pssr_tunables().igemm_big == 2 && a.taps[0] == 9 && a.W >= 16 && a.H >= 16) return launch_geo<T, 64>(a, s);   // 256 x 64 tiles for wide layers too
         }
         return launch_geo<T, 128>(a, s);

@@ -10,6 +10,7 @@ struct PssrTunables {
     int igemm_v3_64;        // the same loop in 16x32-pixel x 64-channel tiles for layers with 33..64 output channels (0 off, 1 on)
     int v3_lds_pad;         // experiment: KiB of unused LDS per v3 workgroup (1 workgroup per CU from ~25)
     int igemm_dbg;          // diagnostic bits of the v3 loop (0 in production)
+    int igemm_n64;          // 128 x 64 tiles for the 3x3 layers whose 128 x 128 tiles would leave one workgroup per CU
     int igemm_ksplit;       // workgroups a split-K launch of the 128-pixel loop aims for
     int conv_epi8;          // straight-line 8-channel epilogue
     int wgrad_lean;         // lean-loader weight-gradient kernel
