@@ -34,7 +34,8 @@ PEAK_HBM_GBS = 8000.0
 # layer-wise roofline time per tile, sum over layers of max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) -> the bound on
 # tiles/s per GPU; `layerwise_bound.frac` = measured / bound is the survey's single headline fraction
 LAYERWISE_BOUND = {"c2_train": 10.6e3, "c2_infer": 31.8e3, "c3_train": 6.0e3, "c3_infer": 18.1e3, "c4_train": 2.6e3, "c4_infer": 7.9e3}
-DOMINANT_SYMBOLS = ("conv_igemm_kernelIDF16bLi128ELi0ELi9E", "conv_v3_kernelIDF16bLi128E")   # the 3x3 loops for Cout > 64 (8x16 / 16x16 tiles)
+# the 3x3 loops for Cout > 64: 16x16-pixel x 128-channel tiles (conv_v3), 8x16 x 128 and -- where those would leave one workgroup per CU -- 8x16 x 64
+DOMINANT_SYMBOLS = ("conv_igemm_kernelIDF16bLi128ELi0ELi9E", "conv_v3_kernelIDF16bLi128E", "conv_igemm_kernelIDF16bLi64ELi0ELi9E")
 
 
 from pssr2_amd.distributed import CooperativeStop  # noqa: E402  (imports torch.distributed only; no HIP call)
@@ -649,7 +650,7 @@ def main():
         traffic, traffic_src = pmc_traffic(args.mode if args.model == "resunet" else f"{args.model}_{args.mode}") if default_workload else (None, None)
         if conv:
             res["roofline"] = {"bound": "mfma", "kernel": "3x3 conv forward + dgrad, Cout > 64 (conv_v3_kernel 16x16-pixel x 128-channel tiles where they fill the chip, "
-                                                          "conv_igemm_kernel 8x16 tiles otherwise)",
+                                                          "conv_igemm_kernel 8x16-pixel tiles of 128 or 64 channels otherwise)",
                                "achieved": round(conv["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(conv["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv["bytes_per_launch"]),
