@@ -435,12 +435,12 @@ class RDEngine(Engine):
             if k == 0 and p.epool is not None:
                 A.psp_forward(self, p.epool, m.encoder_pool, p.cat[0], 0, n, code, p.epool_out, 0, train)
                 src = p.epool_out
-            self._block_forward(p, blk, m.decoder[k], src, src.shape[-1], False, blk.out, 0, train)
             r = m.ratios[k + 1]
-            if k + 1 < nd:
-                ops.pixel_shuffle(blk.out, p.cat[k + 1], n, *p.dims[k], hid[k] // (r * r), r, code)
-            else:
-                ops.pixel_shuffle(blk.out, p.feat, n, *p.dims[k], self.h0, r, code)
+            nxt = p.cat[k + 1] if k + 1 < nd else p.feat
+            # (eval mode, ratio 2: the block's last convolution stores its output shuffled into `nxt` itself -- Engine._block_forward)
+            if self._block_forward(p, blk, m.decoder[k], src, src.shape[-1], False, blk.out, 0, train, shuf=nxt if (r == 2 and not train) else None):
+                continue
+            ops.pixel_shuffle(blk.out, nxt, n, *p.dims[k], hid[k] // (r * r) if k + 1 < nd else self.h0, r, code)
         feat = p.feat
         if p.rpool is not None:
             A.psp_forward(self, p.rpool, m.reconstruction_pool, p.feat, 0, n, code, p.rpool_out, 0, train)

@@ -214,3 +214,31 @@ def test_rd_backward_split_point_gradients_are_final():
     frac = 1.0 - a0 / eng._flat_grad.numel()
     assert frac > 0.3, frac              # a substantial share of the bytes can be reduced under the encoder's backward
     print("tail fraction", frac)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_rd_eval_pixel_shuffle_done_by_the_producing_convolution(monkeypatch, dt):
+    """Eval mode, 16-bit storage: the RDResUNet decoder blocks whose output goes through F.pixel_shuffle(x, 2) (pssr/models/rdresunet.py:122-126)
+    store into the next concat buffer themselves (PSSR_FLAG_SHUF2): bit-identical to the separate shuffle launches."""
+    import pssr2_amd.engine as E
+    from pssr2_amd.models import RDResUNet
+    kw = dict(channels=1, hidden=[64, 64, 64], scale=4, depth=1, rdnet_init=32, growth_rates=[16, 24, 32], ds_blocks=[False, True, True],
+              ese_blocks=[False, True, True], n_blocks=[1, 1, 1])
+    torch.manual_seed(3)
+    ref = RDResUNet(**kw).cuda()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(-1.2, 1.5); m.bias.normal_(0, 0.3)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    x = (torch.rand(2, 1, 32, 32) * 255).cuda()
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "_EVAL_SHUF", fused)
+        model = RDResUNet(**kw).cuda().eval()
+        model.load_state_dict(sd)
+        model.compute_dtype = dt
+        model.infer_dtype = dt
+        with torch.no_grad():
+            outs[fused] = model(x).float().clone()
+    assert torch.isfinite(outs[True]).all() and torch.equal(outs[True], outs[False])
