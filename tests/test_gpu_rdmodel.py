@@ -232,13 +232,24 @@ def test_rd_eval_pixel_shuffle_done_by_the_producing_convolution(monkeypatch, dt
                 m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(-1.2, 1.5); m.bias.normal_(0, 0.3)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
     x = (torch.rand(2, 1, 32, 32) * 255).cuda()
-    outs = {}
+    from pssr2_amd import ops
+    outs, calls = {}, {}
+    real = ops.pixel_shuffle
     for fused in (True, False):
         monkeypatch.setattr(E, "_EVAL_SHUF", fused)
+        count = [0]
+
+        def counting(*a, **k):
+            count[0] += 1
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "pixel_shuffle", counting)
         model = RDResUNet(**kw).cuda().eval()
         model.load_state_dict(sd)
         model.compute_dtype = dt
         model.infer_dtype = dt
         with torch.no_grad():
             outs[fused] = model(x).float().clone()
+        calls[fused] = count[0]
+    monkeypatch.setattr(ops, "pixel_shuffle", real)
+    assert calls[True] < calls[False], calls
     assert torch.isfinite(outs[True]).all() and torch.equal(outs[True], outs[False])
