@@ -121,6 +121,9 @@ enum {
     PSSR_FLAG_AFFINE = 4, /* EPI_STORE, 16-bit storage, not with FLAG_STATS: out = (acc + bias) * aux_scale + aux_shift (then FLAG_RELU):
                              an eval-mode BatchNorm (+ ReLU) applied by the PRODUCING convolution on its f32 accumulators
                              (_blocks.py:28-32 in eval mode), so that the next layer's loader needs no prologue */
+    PSSR_FLAG_SOLO = 32,  /* hint, any epilogue: nothing else runs beside this launch (a forward pass on one stream): tilings that fill the
+                             chip by themselves are preferred -- 128 x 64 tiles where 128 x 128 would leave one workgroup per CU.  Launches
+                             of a backward pass, which share the chip with the weight-gradient stream, measured better without it */
     PSSR_FLAG_SHUF2 = 16  /* EPI_STORE, 16-bit storage, cout % 32 == 0, not with FLAG_STATS / FLAG_HEADQ: F.pixel_shuffle(out, 2)
                              (resunet.py:82) done by the store.  `out` is the [n, 2h, 2w, out_cstride] buffer the shuffled map belongs
                              into (channels out_coff .. out_coff + cout / 4); the weights (and bias) arrive with their output channels

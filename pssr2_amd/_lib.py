@@ -15,7 +15,7 @@ _lib = None
 F32, BF16, F16 = 0, 1, 2
 PRO_NONE, PRO_BN_RELU, PRO_GELU = 0, 1, 2
 EPI_STORE, EPI_TAIL, EPI_DGRAD_MASK, EPI_FINAL, EPI_DGRAD_GELU, EPI_HEADQ = 0, 1, 2, 3, 4, 5
-FLAG_RELU, FLAG_STATS, FLAG_AFFINE, FLAG_HEADQ, FLAG_SHUF2 = 1, 2, 4, 8, 16
+FLAG_RELU, FLAG_STATS, FLAG_AFFINE, FLAG_HEADQ, FLAG_SHUF2, FLAG_SOLO = 1, 2, 4, 8, 16, 32
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -42,7 +42,7 @@ static int conv2d_entry(const pssr_conv_desc* d, pssr_stream_t stream, long* que
         PSSR_CHECK((d->in1_cstride * esz) % 16 == 0 && (d->in1_coff * esz) % 16 == 0 && d->in1_coff + d->cin1 <= d->in1_cstride, PSSR_ERR_ARG, "conv2d: in1 stride/offset");
     }
     if (d->epilogue == PSSR_EPI_FINAL) {
-        PSSR_CHECK(d->cout > 0 && d->cout <= 32 && d->flags == 0, PSSR_ERR_ARG, "conv2d: EPI_FINAL needs 0 < cout <= 32 and no flags");
+        PSSR_CHECK(d->cout > 0 && d->cout <= 32 && (d->flags & ~PSSR_FLAG_SOLO) == 0, PSSR_ERR_ARG, "conv2d: EPI_FINAL needs 0 < cout <= 32 and no flags");
     } else {
         PSSR_CHECK(d->cout > 0 && d->cout % 4 == 0, PSSR_ERR_ARG, "conv2d: cout=%d must be a positive multiple of 4", d->cout);
         PSSR_CHECK(d->out_coff % 4 == 0 && d->out_cstride % 4 == 0 &&

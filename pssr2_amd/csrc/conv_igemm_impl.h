@@ -1122,8 +1122,9 @@ int launch_bn(const ConvArgs& a, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             // layers whose 128 x 128 tiles give about ONE workgroup per CU (512 channels on the 16 x 16 maps at batch 32) take 128 x 64 tiles:
             // two co-resident workgroups cover each other's barriers and staging latency (512 -> 512 @16^2 57.0 -> 45.2 us, 768 -> 512
-            // 72.3 -> 62.8; inside the training step the gain is absorbed, forward-only passes at that batch size run 1.8 % faster)
-            if (pssr_tunables().igemm_n64 && a.taps[0] == 9 && a.W > 8) {
+            // 72.3 -> 62.8).  Only for launches that have the chip to themselves (FLAG_SOLO: forward passes): in the backward pass the wider
+            // launches took from the weight-gradient stream what they gained (kernel trace: forward -33 us, backward +40 us)
+            if (pssr_tunables().igemm_n64 && (a.flags & PSSR_FLAG_SOLO) && a.taps[0] == 9 && a.W > 8) {
                 const long b128 = (long)cdiv(a.W, 16) * cdiv(a.H, 8) * a.N * cdiv(a.cout, 128);
                 if (b128 >= 192 && b128 <= 320) return launch<T, 64, 0>(a, s);
             }

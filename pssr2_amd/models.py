@@ -123,7 +123,12 @@ class _EngineFunction(torch.autograd.Function):
         ctx.param_ids = [id(p) for p in params]
         ctx.shapes = [p.shape for p in params]
         engine._will_backward = any(ctx.needs_input_grad[2:])      # a backward pass can follow: keep what its kernels want prepared
-        return engine.forward(x, engine.model.training)
+        from . import ops
+        ops.SOLO[0] = True          # the forward pass has the device to itself (one stream): PSSR_FLAG_SOLO on its convolutions
+        try:
+            return engine.forward(x, engine.model.training)
+        finally:
+            ops.SOLO[0] = False
 
     @staticmethod
     def backward(ctx, dout):

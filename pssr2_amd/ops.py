@@ -55,6 +55,10 @@ def pack_conv_weight(w: torch.Tensor, dtype: int, mode: int = 0, ci_begin: int =
     return out
 
 
+# [True] while a forward pass issues its launches (Engine.forward): nothing runs beside them, which conv2d passes on as PSSR_FLAG_SOLO
+SOLO = [False]
+
+
 def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_coff=0, bias=None,
            x1=None, cin1=0, w1: PackedWeight | None = None, in1_coff=0,
            pro_scale=None, pro_shift=None, epilogue=L.EPI_STORE, flags=0,
@@ -73,7 +77,7 @@ def conv2d(x, cin0, w0: PackedWeight, out, cout, *, n, h, w, in0_coff=0, out_cof
     d.pro_scale, d.pro_shift = L.ptr(pro_scale), L.ptr(pro_shift)
     d.out, d.out_cstride, d.out_coff, d.cout, d.n_pad = L.ptr(out), out.shape[-1], out_coff, cout, w0.n_pad
     d.bias = L.ptr(bias)
-    d.epilogue, d.flags = epilogue, flags
+    d.epilogue, d.flags = epilogue, flags | (L.FLAG_SOLO if SOLO[0] else 0)
     if aux is not None:
         d.aux, d.aux_cstride, d.aux_coff = L.ptr(aux), aux.shape[-1], aux_coff
     d.aux_scale, d.aux_shift, d.aux_mean, d.aux_invstd = L.ptr(aux_scale), L.ptr(aux_shift), L.ptr(aux_mean), L.ptr(aux_invstd)
